@@ -1,0 +1,310 @@
+/*
+ * p3d.h — C-ABI of the MI355X-native per-pixel ray-trace hot path.
+ *
+ * This is the drop-in boundary.  The reference (fmbnicola/P3D-RayTracer) has no
+ * FFI: the seam is the in-process call that renderScene() (Raytracing/main.cpp:694)
+ * makes once per pixel sample,
+ *     rayTracing(ray, MAX_DEPTH, 1.0, i, j)            main.cpp:795,811
+ *     Radiance  (ray, MAX_DEPTH, 1.0, i, j, seed)      main.cpp:792
+ * against process globals (Scene* scene, Grid grid, BVH bvh: main.cpp:67-69) and the
+ * compile-time option set of constants.h:6-45.  A per-ray FFI is meaningless on a
+ * GPU, so one call here replaces the whole pixel x sample loop body of
+ * main.cpp:747-820 for a tile of the image: primary-ray generation
+ * (camera.h:65-115), closest-hit / any-hit traversal (bvh.cpp:198-340,
+ * grid.cpp:71-208, brute force main.cpp:116-124), the shape tests
+ * (scene.cpp:47-94,116-137,149-186,215-227; boundingBox.cpp:44-98), Whitted
+ * shading (main.cpp:92-309) or the path tracer (main.cpp:313-516), sample
+ * averaging (main.cpp:800), gamma (main.cpp:814-815) and the u8 pack
+ * (maths.h:81-86).
+ *
+ * Plain C types only: no C++ classes, no torch types.  All functions return 0 on
+ * success and a negative p3d_status on failure; they never throw and never
+ * exit().  There is NO CPU fallback behind this ABI: without a HIP device every
+ * render/trace entry point fails with P3D_ERR_NO_DEVICE.
+ */
+#ifndef P3D_H
+#define P3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P3D_ABI_VERSION 1u
+
+typedef enum p3d_status {
+  P3D_OK = 0,
+  P3D_ERR_INVALID = -1,     /* bad argument / inconsistent descriptor           */
+  P3D_ERR_NO_DEVICE = -2,   /* no HIP device, or HIP runtime error (see last_error) */
+  P3D_ERR_UNSUPPORTED = -3, /* option combination not implemented on the device  */
+  P3D_ERR_CAPACITY = -4,    /* traversal stack / scene exceeds device limits     */
+  P3D_ERR_IO = -5           /* .p3f file could not be opened                     */
+} p3d_status;
+
+/* Object kinds of scene.h:101-179 (Sphere, Triangle, aaBox, Plane). */
+typedef enum p3d_prim_type {
+  P3D_PRIM_SPHERE = 0,
+  P3D_PRIM_TRIANGLE = 1,
+  P3D_PRIM_BOX = 2,
+  P3D_PRIM_PLANE = 3
+} p3d_prim_type;
+
+/* constants.h:41 — enum accel_struct {None, UGrid, Bvh}; same numeric values. */
+typedef enum p3d_accel { P3D_ACCEL_NONE = 0, P3D_ACCEL_GRID = 1, P3D_ACCEL_BVH = 2 } p3d_accel;
+/* constants.h:42 — enum sample_mode {jitter, tent}. */
+typedef enum p3d_sample_mode { P3D_SAMPLE_JITTER = 0, P3D_SAMPLE_TENT = 1 } p3d_sample_mode;
+/* constants.h:36 — PATHTRACING false/true. */
+typedef enum p3d_integrator { P3D_WHITTED = 0, P3D_PATHTRACE = 1 } p3d_integrator;
+
+/*
+ * One scene object, in Scene::objects push order (scene.cpp:296-299).  The index
+ * of a record in the array IS the hit ID reported by the renderer.
+ *   sphere   : v[0..2] = center, v[3] = radius                   (scene.h:139-162)
+ *   triangle : v[0..8] = P0,P1,P2 ; n = unit normal as the ctor computes it
+ *              (scene.cpp:17-18) ; bmin/bmax = Min/Max -/+ EPSILON (scene.cpp:21-34)
+ *   box      : v[0..2] = min, v[3..5] = max                      (scene.cpp:205-209)
+ *   plane    : v[0..2] = PN (unit normal), v[3..5] = A            (scene.cpp:102-113)
+ * bmin/bmax hold GetBoundingBox() for every kind (sphere: center -/+ r,
+ * scene.cpp:194-198; plane: the default [-1,1]^3 box, scene.h:114).
+ */
+typedef struct p3d_prim {
+  float v[9];
+  uint32_t type;     /* p3d_prim_type */
+  uint32_t material; /* index into p3d_scene_desc.materials */
+  uint32_t reserved0;
+  float n[3];
+  uint32_t reserved1;
+  float bmin[3];
+  uint32_t reserved2;
+  float bmax[3];
+  uint32_t reserved3;
+} p3d_prim; /* 96 bytes */
+
+/* Material (scene.h:34-71).  reflection == specular: m_Refl = Ks (scene.h:42). */
+typedef struct p3d_material {
+  float diff_color[3];
+  float diffuse;      /* Kd */
+  float spec_color[3];
+  float specular;     /* Ks */
+  float shine;
+  float transmittance; /* T */
+  float refr_index;    /* ior */
+  float reflection;    /* = Ks */
+  float emission[3];
+  float reserved;
+} p3d_material; /* 64 bytes */
+
+/* Light (scene.h:73-81). */
+typedef struct p3d_light {
+  float position[3];
+  float reserved0;
+  float color[3];
+  float reserved1;
+} p3d_light; /* 32 bytes */
+
+/* Camera state after the constructor of camera.h:34-63 has run. */
+typedef struct p3d_camera {
+  float eye[3];
+  float plane_dist;
+  float u[3];
+  float w;           /* view-window width  */
+  float v[3];
+  float h;           /* view-window height */
+  float n[3];
+  float focal_ratio;
+  float aperture;    /* Aperture_ratio * (w / res_x), camera.h:59 */
+  int32_t res_x;
+  int32_t res_y;
+  int32_t reserved;
+} p3d_camera; /* 80 bytes */
+
+/*
+ * BVH node, 32 bytes, in the order BVH::build_recursive pushes them
+ * (bvh.cpp:185-194): node 0 is the root and the two children of an inner node
+ * are adjacent at [index, index+1].
+ *   inner: count_leaf == 0,                 index = left child
+ *   leaf : count_leaf = 0x80000000 | n_objs, index = first entry in bvh_prim_index
+ */
+typedef struct p3d_bvh_node {
+  float bmin[3];
+  uint32_t index;
+  float bmax[3];
+  uint32_t count_leaf;
+} p3d_bvh_node;
+#define P3D_BVH_LEAF 0x80000000u
+
+/* Uniform grid as Grid::Build lays it out (grid.cpp:3-68): cell (ix,iy,iz) is
+ * entry ix + nx*iy + nx*ny*iz; its objects are cell_items[cell_start[c] ..
+ * cell_start[c+1]) in insertion (= object) order. */
+typedef struct p3d_grid_desc {
+  float bmin[3];
+  int32_t nx;
+  float bmax[3];
+  int32_t ny;
+  int32_t nz;
+  uint32_t n_cells;          /* nx*ny*nz */
+  uint32_t n_items;          /* cell_start[n_cells] */
+  uint32_t reserved;
+  const uint32_t* cell_start; /* n_cells + 1 entries */
+  const uint32_t* cell_items; /* object indices */
+} p3d_grid_desc;
+
+/* Everything the device needs; all arrays are host memory owned by the caller
+ * and are copied by p3d_scene_create. */
+typedef struct p3d_scene_desc {
+  uint32_t abi_version; /* P3D_ABI_VERSION */
+  uint32_t n_prims;
+  uint32_t n_materials;
+  uint32_t n_lights;
+  const p3d_prim* prims;
+  const p3d_material* materials;
+  const p3d_light* lights;
+  p3d_camera camera;
+  float background[3];       /* bclr, Scene::GetBackgroundColor (scene.h:189) */
+  uint32_t n_bvh_nodes;      /* 0 = no BVH supplied */
+  const p3d_bvh_node* bvh_nodes;
+  const uint32_t* bvh_prim_index; /* permuted BVH::objs (bvh.cpp:84), object indices */
+  uint32_t n_bvh_prim_index;
+  uint32_t bvh_max_depth;    /* levels, root = 1 */
+  uint32_t has_grid;
+  uint32_t reserved;
+  p3d_grid_desc grid;
+} p3d_scene_desc;
+
+/* Runtime form of the compile-time options of constants.h:6-45.  p3d_config_default()
+ * fills in the reference's shipped values (SKYBOX is not implemented: a miss
+ * returns the background colour, i.e. SKYBOX false, main.cpp:145-146). */
+typedef struct p3d_config {
+  uint32_t integrator;    /* PATHTRACING        constants.h:36  */
+  uint32_t accel;         /* acl_str            constants.h:44  */
+  int32_t max_depth;      /* MAX_DEPTH          constants.h:6   */
+  uint32_t spp_sqrt;      /* SPP (sqrt of spp)  constants.h:12  */
+  uint32_t antialiasing;  /* ANTIALIASING       constants.h:24  */
+  uint32_t depth_of_field;/* DEPTH_OF_FIELD     constants.h:27  */
+  uint32_t sample_disk;   /* SAMPLE_DISK        constants.h:21  */
+  uint32_t soft_shadows;  /* SOFT_SHADOWS       constants.h:9   */
+  uint32_t sample_mode;   /* s_mode             constants.h:45  */
+  float light_side;       /* LIGHT_SIDE         constants.h:15  */
+  float gamma;            /* GAMMA              constants.h:38  */
+  uint32_t collect_stats; /* 1: fill the test/ray counters of p3d_stats (slower kernel) */
+  uint64_t seed;          /* replaces set_rand_seed(time*time), main.cpp:722:
+                             every (pixel, sample) draws from its own stream */
+} p3d_config;
+
+/*
+ * Region of the image a call renders.  Rows are numbered as the reference
+ * numbers them: y = 0 is the BOTTOM image row (main.cpp:747, camera.h:71).
+ * Local row r of the output buffers maps to image row
+ *     y = y0 + (r / stripe_h) * stripe_h * stripe_stride + (r % stripe_h)
+ * so that one rank of an N-rank job renders every N-th stripe of stripe_h rows
+ * (stripe_stride = N, y0 = rank * stripe_h); stripe_stride = 1 (or stripe_h = 0)
+ * is a plain rectangle.  Output buffers are w*h, local row 0 first.
+ */
+typedef struct p3d_tile {
+  int32_t x0, y0, w, h;
+  int32_t stripe_h;
+  int32_t stripe_stride;
+} p3d_tile;
+
+/* Counters of one call.  A "ray" is one traversal query (closest-hit or
+ * any-hit).  The test counters feed the algorithmic-bytes figure of DESIGN.md. */
+typedef struct p3d_stats {
+  uint64_t rays_primary;
+  uint64_t rays_shadow;
+  uint64_t rays_reflect;
+  uint64_t rays_refract;
+  uint64_t rays_bounce;  /* path-tracer continuation rays */
+  uint64_t rays_light;   /* path-tracer light-visibility rays */
+  uint64_t node_tests;   /* AABB::intercepts calls on BVH nodes */
+  uint64_t sphere_tests;
+  uint64_t tri_tests;
+  uint64_t box_tests;
+  uint64_t plane_tests;
+  uint64_t shaded_hits;
+  uint64_t pixels;
+  uint64_t max_stack;    /* deepest traversal stack seen (entries) */
+  double kernel_ms;      /* HIP-event time of the kernel(s) of this call */
+} p3d_stats;
+
+typedef struct p3d_scene p3d_scene; /* device-resident scene, one per HIP device */
+
+/* ---- library ---- */
+uint32_t p3d_abi_version(void);
+const char* p3d_last_error(void);          /* thread-local message of the last failure */
+int p3d_device_count(void);                /* >= 0, or negative p3d_status */
+void p3d_config_default(p3d_config* cfg);  /* constants.h:6-45 as shipped */
+
+/* ---- scene on the device ---- */
+/* Uploads the flattened scene to HBM of HIP device `device` (arrays copied). */
+int p3d_scene_create(const p3d_scene_desc* desc, int device, p3d_scene** out);
+void p3d_scene_destroy(p3d_scene* scene);
+
+/* ---- the hot path ---- */
+/*
+ * Renders one tile.  Replaces the loop body main.cpp:753-820 for every pixel of
+ * the tile.  Host-buffer form: synchronous; any output pointer may be NULL.
+ *   rgb    : w*h*3 float, linear colour after sample averaging (main.cpp:800),
+ *            BEFORE gamma
+ *   hit_id : w*h int32, object index hit by the pixel's first primary ray, -1 = miss
+ *   rgb8   : w*h*3 uint8, after gamma + u8fromfloat (main.cpp:814-820) = img_Data
+ */
+int p3d_render_tile(p3d_scene* scene, const p3d_config* cfg, const p3d_tile* tile,
+                    float* rgb, int32_t* hit_id, uint8_t* rgb8, p3d_stats* stats);
+/*
+ * Device-buffer form: the output pointers are HBM addresses on the scene's
+ * device; the kernel is enqueued on `hip_stream` (a hipStream_t, NULL = default
+ * stream) and the call returns without synchronising unless `stats` is non-NULL
+ * (then it waits for the kernel and fills kernel_ms and, with
+ * cfg->collect_stats, the counters).
+ */
+int p3d_render_tile_device(p3d_scene* scene, const p3d_config* cfg, const p3d_tile* tile,
+                           float* d_rgb, int32_t* d_hit_id, uint8_t* d_rgb8,
+                           void* hip_stream, p3d_stats* stats);
+
+/*
+ * Batched traversal queries — device counterparts of BVH::intersect_bvh
+ * (bvh.cpp:198), Grid::Traverse (grid.cpp:71) and the brute-force loop
+ * (main.cpp:116-124) for closest hit, and of BVH::bool_intersect_bvh
+ * (bvh.cpp:278), Grid::Traverse(ray) (grid.cpp:154) and main.cpp:208-216 for any
+ * hit.  Every ray starts with an empty traversal stack.  Host buffers:
+ *   origin, direction : n*3 float (direction used as given, not normalised)
+ *   hit_id : n int32 (-1 = miss) ; t : n float ; hit_point : n*3 float (may be NULL)
+ *   occluded : n uint8
+ */
+int p3d_trace_closest(p3d_scene* scene, uint32_t accel, uint32_t n, const float* origin,
+                      const float* direction, int32_t* hit_id, float* t, float* hit_point);
+int p3d_trace_any(p3d_scene* scene, uint32_t accel, uint32_t n, const float* origin,
+                  const float* direction, uint8_t* occluded);
+
+/* ---- host side: .p3f loader and acceleration-structure builders ---- */
+/*
+ * Host scene = Scene::load_p3f (scene.cpp:472-628) + the accel builds that
+ * renderScene() does first (main.cpp:701-720): BVH::build (bvh.cpp:89-196) and
+ * Grid::Build (grid.cpp:3-68).  These run on the host (as they do in the
+ * reference) and produce the flat p3d_scene_desc that p3d_scene_create uploads.
+ */
+typedef struct p3d_host_scene p3d_host_scene;
+
+#define P3D_LOAD_LEGACY_F11 1u /* accept the older 11-number `f` line (no emission);
+                                  the shipped parser breaks on it */
+
+int p3d_host_scene_load(const char* p3f_path, uint32_t flags, p3d_host_scene** out);
+void p3d_host_scene_destroy(p3d_host_scene* hs);
+/* Re-runs the Camera constructor (camera.h:34-63) with another resolution —
+ * what editing the `resolution` line of the .p3f would do.  rx,ry <= 0 keeps. */
+int p3d_host_scene_set_resolution(p3d_host_scene* hs, int32_t res_x, int32_t res_y);
+/* Same for the `aperture` / `focal` entries of the `v` block. */
+int p3d_host_scene_set_lens(p3d_host_scene* hs, float aperture_ratio, float focal_ratio);
+/* Replaces every light by SPP x SPP jittered copies (main.cpp:725-745); used for
+ * SOFT_SHADOWS without ANTIALIASING. */
+int p3d_host_scene_replicate_lights(p3d_host_scene* hs, uint32_t spp_sqrt, float light_side);
+/* Builds (once) the requested structures and returns the descriptor; the
+ * pointer stays valid until the host scene is destroyed or modified. */
+int p3d_host_scene_desc(p3d_host_scene* hs, int build_bvh, int build_grid,
+                        const p3d_scene_desc** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P3D_H */
