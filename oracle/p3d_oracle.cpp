@@ -1661,6 +1661,59 @@ int orc_trace_any(void* s, int accel, int n, const float* o, const float* d, uin
   }
   return 0;
 }
+
+// ---- L0 unit entry points (pinned against oracle/_ref, tests/test_oracle_ref_vectors.py) ----
+void orc_vec_normalize(float* v) { V3 a = v3(v[0], v[1], v[2]); normalize(a); v[0] = a.x; v[1] = a.y; v[2] = a.z; }
+float orc_vec_length(const float* v) { return length(v3(v[0], v[1], v[2])); }
+float orc_vec_dot(const float* a, const float* b) { return dot(v3(a[0], a[1], a[2]), v3(b[0], b[1], b[2])); }
+void orc_vec_cross(const float* a, const float* b, float* o) {
+  V3 r = cross(v3(a[0], a[1], a[2]), v3(b[0], b[1], b[2]));
+  o[0] = r.x; o[1] = r.y; o[2] = r.z;
+}
+void orc_vec_div(const float* a, float f, float* o) {
+  V3 r = v3(a[0], a[1], a[2]) / f;
+  o[0] = r.x; o[1] = r.y; o[2] = r.z;
+}
+void orc_get_direction(float* d, int k) {
+  Ray r;
+  r.d = v3(d[0], d[1], d[2]);
+  for (int i = 0; i < k; i++) get_direction(r);
+  d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z;
+}
+// camera from explicit `v`-block values; returns aperture and plane_dist in state2
+void orc_camera_rays(const float* p15, int n, const float* px2, const float* lens2, float* ray_o,
+                     float* ray_d, float* lray_o, float* lray_d, float* state2) {
+  Camera c;
+  c.init(v3(p15[0], p15[1], p15[2]), v3(p15[3], p15[4], p15[5]), v3(p15[6], p15[7], p15[8]), p15[9],
+         p15[10], (float)(100.0 * p15[10]), (int)p15[11], (int)p15[12], p15[13], p15[14]);
+  state2[0] = c.aperture; state2[1] = c.plane_dist;
+  for (int i = 0; i < n; i++) {
+    Ray r = c.primary(v3(px2[2 * i], px2[2 * i + 1], 0));
+    ray_o[3 * i] = r.o.x; ray_o[3 * i + 1] = r.o.y; ray_o[3 * i + 2] = r.o.z;
+    ray_d[3 * i] = r.d.x; ray_d[3 * i + 1] = r.d.y; ray_d[3 * i + 2] = r.d.z;
+    Ray q = c.primary_lens(v3(lens2[2 * i], lens2[2 * i + 1], 0), v3(px2[2 * i], px2[2 * i + 1], 0));
+    lray_o[3 * i] = q.o.x; lray_o[3 * i + 1] = q.o.y; lray_o[3 * i + 2] = q.o.z;
+    lray_d[3 * i] = q.d.x; lray_d[3 * i + 1] = q.d.y; lray_d[3 * i + 2] = q.d.z;
+  }
+}
+// rand_float / sample_unit_disk on the libc stream (rng_mode 1)
+void orc_libc_rand_floats(unsigned seed, int n, float* out) {
+  Rng r; r.mode = 1;
+  srand(seed);
+  for (int i = 0; i < n; i++) out[i] = r.rand_float();
+}
+void orc_libc_unit_disk(unsigned seed, int n, int eval_order, float* out2) {
+  Ctx cx;
+  cx.sc = nullptr;
+  orc_config_default(&cx.cfg);
+  cx.cfg.eval_order = eval_order;
+  cx.rng.mode = 1;
+  srand(seed);
+  for (int i = 0; i < n; i++) { V3 p = sample_unit_disk(cx); out2[2 * i] = p.x; out2[2 * i + 1] = p.y; }
+}
+void orc_color_clamp(float* c) { C3 k = clamp(c3(c[0], c[1], c[2])); c[0] = k.r; c[1] = k.g; c[2] = k.b; }
+float orc_u8tofloat(uint8_t x) { return (float)(x / 255.99f); }  // maths.h:89-92
+
 double orc_det_sin(double x) { return det_sin(x); }
 double orc_det_cos(double x) { return det_cos(x); }
 int orc_rng_stream(uint64_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out) {

@@ -100,6 +100,19 @@ int orc_primary_ray_lens(void* s, float lx, float ly, float px, float py, float*
 int orc_trace_closest(void* s, int accel, int n, const float* o, const float* d, int32_t* hit,
                       float* t, float* hit_point);
 int orc_trace_any(void* s, int accel, int n, const float* o, const float* d, uint8_t* occluded);
+/* L0 restatements (vector.cpp, ray.h:16-18, camera.h:34-115, maths.h:67-92, sampler.cpp:5-11, color.h:39-44) */
+void orc_vec_normalize(float* v3);
+float orc_vec_length(const float* v3);
+float orc_vec_dot(const float* a3, const float* b3);
+void orc_vec_cross(const float* a3, const float* b3, float* out3);
+void orc_vec_div(const float* a3, float f, float* out3);
+void orc_get_direction(float* d3, int k);
+void orc_camera_rays(const float* p15, int n, const float* px2, const float* lens2, float* ray_o,
+                     float* ray_d, float* lray_o, float* lray_d, float* state2);
+void orc_libc_rand_floats(unsigned seed, int n, float* out);
+void orc_libc_unit_disk(unsigned seed, int n, int eval_order, float* out2);
+void orc_color_clamp(float* c3);
+float orc_u8tofloat(uint8_t x);
 /* deterministic sin/cos used by both sides (see p3d_oracle.cpp "detmath") */
 double orc_det_sin(double x);
 double orc_det_cos(double x);

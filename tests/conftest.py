@@ -1,0 +1,39 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SCENES = os.path.join(GOLDEN, "scenes")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU test")
+
+
+def scene_path(name):
+    return os.path.join(SCENES, name)
+
+
+@pytest.fixture(scope="session")
+def tri100k_path(tmp_path_factory):
+    """The synthetic 100k-triangle scene of BASELINE configs[3] (generated, ~9 MB of text)."""
+    sys.path.insert(0, os.path.join(ROOT, "scenes"))
+    import make_tri100k
+    p = str(tmp_path_factory.mktemp("scenes") / "tri100k.p3f")
+    make_tri100k.generate(p)
+    return p
+
+
+@pytest.fixture(scope="session")
+def tri5k_path(tmp_path_factory):
+    sys.path.insert(0, os.path.join(ROOT, "scenes"))
+    import make_tri100k
+    p = str(tmp_path_factory.mktemp("scenes") / "tri5k.p3f")
+    make_tri100k.generate(p, n=5000, res=256)
+    return p
