@@ -1,0 +1,624 @@
+// device_core.hpp — CDNA4 device code shared by the Whitted and path-tracing kernels:
+// float3 arithmetic with the reference's exact operation order, the shape tests, and the
+// three traversal back ends.  gfx950 only; compiled with -ffp-contract=off so that no
+// multiply-add is fused: every + - * / sqrt below rounds exactly where
+// the reference's scalar code rounds.
+//
+// Conventions
+//   * A wavefront (64 lanes) is one packet of rays = an 8x8 pixel block.  Traversal is
+//     PER LANE (own current node, own stack): the reference's any-hit traversal is
+//     order-dependent, so lanes cannot share a stack.  The wave as a
+//     whole iterates `while any lane is still walking`.
+//   * The per-lane node stack lives in LDS, entry e of lane l at  stack[e * kBlock + l]
+//     (8 bytes: node index, entry distance).  A wave's 64 lanes then cover all 64 banks
+//     exactly twice per ds_read_b64/ds_write_b64 whatever their individual depths are,
+//     i.e. the access is bank-conflict free by construction.
+//   * Small scenes (every packaged .p3f) are staged into LDS once per workgroup; large
+//     ones (100k triangles = 8.8 MB) are read through L1/L2 from the linearised arrays.
+//   * Mixed-precision literals of the reference are folded into float comparisons where
+//     that is exact (see the cmp_* helpers); real double arithmetic stays double.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "p3d.h"
+
+namespace p3d {
+
+constexpr int kBlock = 64;  // one wavefront per workgroup
+
+// ---------------------------------------------------------------------------
+// float3 with the operation order of vector.cpp
+// ---------------------------------------------------------------------------
+struct F3 {
+  float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float f) { return f3(a.x * f, a.y * f, a.z * f); }
+__device__ __forceinline__ F3 operator/(F3 a, float f) { return f3(a.x / f, a.y / f, a.z / f); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }  // Color*Color
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vector.cpp:55
+__device__ __forceinline__ F3 cross(F3 u, F3 v) {                                               // vector.cpp:84-99
+  return f3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+__device__ __forceinline__ float length(F3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+// vector.cpp:65-70: l = 1.0 / length() is a double division narrowed to float.  For a
+// float divisor that equals the correctly rounded float quotient 1.0f / len (53 >= 2*24+2
+// bits: double rounding is innocuous), which is what IEEE-exact v_div gives.
+__device__ __forceinline__ F3 normalized(F3 a) {
+  const float l = 1.0f / length(a);
+  return f3(a.x * l, a.y * l, a.z * l);
+}
+__device__ __forceinline__ bool same_bits(F3 a, F3 b) {
+  return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+         __float_as_uint(a.z) == __float_as_uint(b.z);
+}
+__device__ __forceinline__ F3 xyz(float4 v) { return f3(v.x, v.y, v.z); }
+
+// color.h:10,39-44 CLAMP(0.0, v, 1.0): NaN passes through
+__device__ __forceinline__ float clamp01(float v) { return (v < 0.0f) ? 0.0f : ((v > 1.0f) ? 1.0f : v); }
+__device__ __forceinline__ F3 clamp01(F3 c) { return f3(clamp01(c.x), clamp01(c.y), clamp01(c.z)); }
+
+// Comparisons of a float against a DOUBLE literal, folded to float exactly:
+//   (double)t <  0.0001  <=>  t <= 0.0001f   (0.0001f is the float just below 1e-4)
+//   (double)t >  0.0001  <=>  t >  0.0001f
+//   (double)a >  0.1     <=>  a >= 0.1f      (0.1f is the float just above 0.1)
+__device__ __forceinline__ bool lt_1em4(float t) { return t <= 0.0001f; }
+__device__ __forceinline__ bool gt_1em4(float t) { return t > 0.0001f; }
+__device__ __forceinline__ bool gt_0p1(float a) { return a >= 0.1f; }
+
+// scene.h:17-22 MIN3 / MAX3 as written (select chains; NaN-order sensitive, unlike v_max3)
+__device__ __forceinline__ float max3_ref(float a, float b, float c) {
+  return (a > b) ? ((a > c) ? a : c) : ((b > c) ? b : c);
+}
+__device__ __forceinline__ float min3_ref(float a, float b, float c) {
+  return (a < b) ? ((a < c) ? a : c) : ((b < c) ? b : c);
+}
+
+// ---------------------------------------------------------------------------
+// Ray with the mutable direction of ray.h:16-18 (Q8).  `inv` caches 1.0f/d for the slab
+// test (boundingBox.cpp:57,67,77 recompute it per test; the value is the same until the
+// direction is re-normalised).  `settled` is set once a re-normalisation left the bits
+// unchanged: normalize() is a pure function of d, so from then on it is the identity.
+// ---------------------------------------------------------------------------
+struct RayS {
+  F3 o, d, inv;
+  bool settled;
+};
+__device__ __forceinline__ void ray_set(RayS& r, F3 o, F3 d) {
+  r.o = o;
+  r.d = d;
+  r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  r.settled = false;
+}
+__device__ __forceinline__ F3 get_direction(RayS& r) {
+  if (!r.settled) {
+    const F3 n = normalized(r.d);
+    if (same_bits(n, r.d)) {
+      r.settled = true;
+    } else {
+      r.d = n;
+      r.inv = f3(1.0f / n.x, 1.0f / n.y, 1.0f / n.z);
+    }
+  }
+  return r.d;
+}
+
+// ---------------------------------------------------------------------------
+// Counters (only in the STATS instantiation)
+// ---------------------------------------------------------------------------
+enum StatSlot {
+  kRaysPrimary = 0, kRaysShadow, kRaysReflect, kRaysRefract, kRaysBounce, kRaysLight,
+  kNodeTests, kSphereTests, kTriTests, kBoxTests, kPlaneTests, kShadedHits, kPixels, kMaxStack,
+  kNumStats
+};
+template <bool ON>
+struct Counters {
+  __device__ __forceinline__ void add(int, uint32_t = 1) {}
+  __device__ __forceinline__ void stack_depth(int) {}
+};
+template <>
+struct Counters<true> {
+  uint32_t c[kNumStats];
+  __device__ __forceinline__ void clear() {
+    for (int i = 0; i < kNumStats; ++i) c[i] = 0;
+  }
+  __device__ __forceinline__ void add(int slot, uint32_t n = 1) { c[slot] += n; }
+  __device__ __forceinline__ void stack_depth(int d) {
+    if ((uint32_t)d > c[kMaxStack]) c[kMaxStack] = d;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// Device scene.  All arrays are float4-granular so every fetch is a 16-byte load
+// (global_load_dwordx4 / ds_read_b128).
+//   nodes    : 2 x float4 per BVH node   {bmin.xyz, index} {bmax.xyz, count_leaf}
+//   bgeom    : 3 x float4 per BVH leaf slot (geometry gathered into leaf order)
+//   ogeom    : 3 x float4 per object (object order: brute force + grid)
+//              {v0..v3} {v4..v7} {v8, type | material << 8, object id, -}
+//   normals  : 1 x float4 per object (triangle unit normal)
+//   mats     : 4 x float4  {cd, Kd} {cs, Ks} {shine, T, ior, refl} {emission, -}
+//   lights   : 2 x float4  {pos, -} {col, -}
+// ---------------------------------------------------------------------------
+struct DevCamera {
+  F3 eye, u, v, n;
+  float w, h, plane_dist, focal_ratio, aperture;
+  int res_x, res_y;
+};
+struct DevGrid {
+  F3 bmin, bmax;
+  int nx, ny, nz;
+  const uint32_t* cell_start;
+  const uint32_t* cell_items;
+};
+struct DevScene {
+  const float4* nodes;
+  const float4* bgeom;
+  const float4* ogeom;
+  const float4* normals;
+  const float4* mats;
+  const float4* lights;
+  const uint32_t* emitters;  // object ids of emissive spheres, object order (main.cpp:407-415)
+  uint32_t n_nodes, n_slots, n_objs, n_mats, n_lights, n_emitters;
+  DevCamera cam;
+  F3 bg;
+  DevGrid grid;
+};
+
+// Per-lane traversal stack (bvh.cpp:86 hit_stack, one per pixel instead of one per process:
+// see DESIGN.md "Sequential state").  The first `cap` entries live in LDS; deeper entries
+// (rare: the worst case is (lights+1)*(tree depth-1), typical depth is a handful) spill to
+// a per-thread column of a global scratch array, so no launch ever has to be repeated.
+struct Stack {
+  uint2* base;   // LDS: &stack[lane]; entry e at base[e * kBlock]
+  uint2* spill;  // global: &spill[thread]; entry cap+e at spill[e * spill_stride]
+  uint32_t spill_stride;
+  int sp;
+  int cap;
+};
+template <class CT>
+__device__ __forceinline__ void push(Stack& s, uint32_t node, float t, CT& ct) {
+  const uint2 e = make_uint2(node, __float_as_uint(t));
+  if (s.sp < s.cap) s.base[s.sp * kBlock] = e;
+  else s.spill[(size_t)(s.sp - s.cap) * s.spill_stride] = e;
+  ++s.sp;
+  ct.stack_depth(s.sp);
+}
+__device__ __forceinline__ uint2 stack_read(const Stack& s, int i) {
+  return (i < s.cap) ? s.base[i * kBlock] : s.spill[(size_t)(i - s.cap) * s.spill_stride];
+}
+
+struct Geom {
+  float4 a, b, c;
+};
+__device__ __forceinline__ Geom load_geom(const float4* g, uint32_t slot) {
+  Geom r;
+  r.a = g[3 * slot];
+  r.b = g[3 * slot + 1];
+  r.c = g[3 * slot + 2];
+  return r;
+}
+__device__ __forceinline__ uint32_t geom_type(const Geom& g) { return __float_as_uint(g.c.y) & 0xffu; }
+__device__ __forceinline__ uint32_t geom_material(const Geom& g) { return __float_as_uint(g.c.y) >> 8; }
+__device__ __forceinline__ uint32_t geom_object(const Geom& g) { return __float_as_uint(g.c.z); }
+
+// boundingBox.cpp:44-98.  Raw direction; t0 < t1 strict; t1 > 0.0001 (double literal).
+__device__ __forceinline__ bool aabb_intercepts(F3 mn, F3 mx, const RayS& r, float& t) {
+  const float a = r.inv.x, b = r.inv.y, c = r.inv.z;
+  const float tx_min = ((a >= 0 ? mn.x : mx.x) - r.o.x) * a, tx_max = ((a >= 0 ? mx.x : mn.x) - r.o.x) * a;
+  const float ty_min = ((b >= 0 ? mn.y : mx.y) - r.o.y) * b, ty_max = ((b >= 0 ? mx.y : mn.y) - r.o.y) * b;
+  const float tz_min = ((c >= 0 ? mn.z : mx.z) - r.o.z) * c, tz_max = ((c >= 0 ? mx.z : mn.z) - r.o.z) * c;
+  const float t0 = max3_ref(tx_min, ty_min, tz_min);
+  const float t1 = min3_ref(tx_max, ty_max, tz_max);
+  t = (t0 < 0) ? t1 : t0;
+  return (t0 < t1) && gt_1em4(t1);
+}
+__device__ __forceinline__ bool is_inside(F3 mn, F3 mx, F3 p) {  // boundingBox.cpp:39-42 (strict)
+  return (p.x > mn.x && p.x < mx.x) && (p.y > mn.y && p.y < mx.y) && (p.z > mn.z && p.z < mx.z);
+}
+
+// Object::intercepts for the four kinds.  The ray is taken by reference: the sphere test
+// re-normalises its direction in place (scene.cpp:156, Q8).
+template <class CT>
+__device__ __forceinline__ bool intercepts(const Geom& g, RayS& ray, float& time, CT& ct) {
+  const uint32_t type = geom_type(g);
+  if (type == P3D_PRIM_TRIANGLE) {  // scene.cpp:47-94
+    ct.add(kTriTests);
+    const F3 P0 = f3(g.a.x, g.a.y, g.a.z), P1 = f3(g.a.w, g.b.x, g.b.y), P2 = f3(g.b.z, g.b.w, g.c.x);
+    const float a = P0.x - P1.x, b = P0.x - P2.x, c = ray.d.x, d = P0.x - ray.o.x;
+    const float e = P0.y - P1.y, f = P0.y - P2.y, gg = ray.d.y, h = P0.y - ray.o.y;
+    const float i = P0.z - P1.z, j = P0.z - P2.z, k = ray.d.z, l = P0.z - ray.o.z;
+    const float m = f * k - gg * j, n = h * k - gg * l, p = f * l - h * j;
+    const float q = gg * i - e * k, s = e * j - f * i;
+    const float inv_denom = 1.0f / (a * m + b * q + c * s);  // 1.0/x narrowed == 1.0f/x
+    const float e1 = d * m - b * n - c * p;
+    const float beta = e1 * inv_denom;
+    if (beta < 0.0f) return false;
+    const float r = e * l - h * i;
+    const float e2 = a * n + d * q + c * r;
+    const float gamma = e2 * inv_denom;
+    if (gamma < 0.0f) return false;
+    if (beta + gamma > 1.0f) return false;
+    const float e3 = a * p - b * r + d * s;
+    const float t = e3 * inv_denom;
+    if (lt_1em4(t)) return false;
+    time = t;  // a NaN t passes every rejection and is reported as a hit (A10)
+    return true;
+  } else if (type == P3D_PRIM_SPHERE) {  // scene.cpp:149-186
+    ct.add(kSphereTests);
+    const F3 Rd = get_direction(ray);
+    const F3 co = f3(g.a.x, g.a.y, g.a.z) - ray.o;
+    const float doc2 = co.x * co.x + co.y * co.y + co.z * co.z;
+    const float b = dot(co, Rd);
+    const float c = doc2 - g.a.w * g.a.w;
+    if (c > 0 && b < 0) return false;
+    const float discriminant = b * b - c;
+    if (discriminant < 0) return false;
+    time = (c > 0) ? b - sqrtf(discriminant) : b + sqrtf(discriminant);
+    return true;
+  } else if (type == P3D_PRIM_BOX) {  // scene.cpp:215-227
+    ct.add(kBoxTests);
+    return aabb_intercepts(f3(g.a.x, g.a.y, g.a.z), f3(g.a.w, g.b.x, g.b.y), ray, time);
+  } else {  // plane, scene.cpp:116-137
+    ct.add(kPlaneTests);
+    const F3 PN = f3(g.a.x, g.a.y, g.a.z), A = f3(g.a.w, g.b.x, g.b.y);
+    const float numer = dot(ray.o - A, PN);
+    const float divid = dot(PN, ray.d);
+    if (fabsf(divid) <= 0.0001f) return false;  // fabs(divid) < 0.0001 (double literal)
+    time = -(numer / divid);
+    return !(time <= 0);
+  }
+}
+
+// Object::getNormal (scene.cpp:41-44,139-142,188-192,229-267)
+__device__ __forceinline__ F3 get_normal(const Geom& g, const float4* normals, F3 point) {
+  const uint32_t type = geom_type(g);
+  if (type == P3D_PRIM_SPHERE) return normalized(point - f3(g.a.x, g.a.y, g.a.z));
+  if (type == P3D_PRIM_TRIANGLE) return xyz(normals[geom_object(g)]);
+  if (type == P3D_PRIM_PLANE) return f3(g.a.x, g.a.y, g.a.z);
+  const F3 mn = f3(g.a.x, g.a.y, g.a.z), mx = f3(g.a.w, g.b.x, g.b.y);
+  const F3 co = point - (mx + mn) / 2;
+  int dir = (fabsf(co.x) > fabsf(co.y)) ? 0 : 1;
+  if (dir == 0 && fabsf(co.z) > fabsf(co.x)) dir = 2;
+  else if (dir == 1 && fabsf(co.z) > fabsf(co.y)) dir = 2;
+  if (dir == 0) return f3(co.x >= 0 ? 1.f : -1.f, 0, 0);
+  if (dir == 1) return f3(0, co.y >= 0 ? 1.f : -1.f, 0);
+  return f3(0, 0, co.z >= 0 ? 1.f : -1.f);
+}
+
+// ---------------------------------------------------------------------------
+// BVH traversal — bvh.cpp:198-340.
+// A node record is two float4s; both children of an inner node are adjacent, so one
+// inner-node visit fetches 64 contiguous bytes.
+// ---------------------------------------------------------------------------
+struct NodeRec {
+  float4 lo, hi;  // {bmin, index} {bmax, count_leaf}
+};
+__device__ __forceinline__ NodeRec load_node(const float4* nodes, uint32_t i) {
+  NodeRec n;
+  n.lo = nodes[2 * i];
+  n.hi = nodes[2 * i + 1];
+  return n;
+}
+
+// Closest hit.  `ray` is the traversal's private copy (bvh.cpp:198 takes Ray by value).
+// Returns the leaf slot of the hit (-1 = miss) and the hit point d*tmin + o (bvh.cpp:271).
+template <class CT>
+__device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_point, Geom& hit_geom, CT& ct) {
+  float tmp, tmin = FLT_MAX;
+  int hit = -1;
+  NodeRec cur = load_node(sc.nodes, 0);
+  ct.add(kNodeTests);
+  if (!aabb_intercepts(xyz(cur.lo), xyz(cur.hi), ray, tmp)) return -1;  // stale entries stay (Q2)
+  while (true) {
+    const uint32_t index = __float_as_uint(cur.lo.w), cl = __float_as_uint(cur.hi.w);
+    bool descended = false;
+    if (!(cl & P3D_BVH_LEAF)) {
+      const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
+      float l_t, r_t;
+      ct.add(kNodeTests, 2);
+      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t);
+      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t);
+      if (is_inside(xyz(l.lo), xyz(l.hi), ray.o)) l_t = 0;  // bvh.cpp:216-217
+      if (is_inside(xyz(r.lo), xyz(r.hi), ray.o)) r_t = 0;
+      if (l_hit && r_hit) {
+        if (l_t < r_t) { cur = l; push(st, index + 1, r_t, ct); }
+        else           { cur = r; push(st, index, l_t, ct); }  // ties go right (Q10)
+        descended = true;
+      } else if (l_hit) { cur = l; descended = true; }
+      else if (r_hit)   { cur = r; descended = true; }
+    } else {
+      const uint32_t n = cl & ~P3D_BVH_LEAF;
+      for (uint32_t s = index; s < index + n; ++s) {
+        const Geom g = load_geom(sc.bgeom, s);
+        float curr_t;
+        if (intercepts(g, ray, curr_t, ct) && curr_t < tmin) {
+          tmin = curr_t;
+          hit = (int)s;
+          hit_geom = g;
+        }
+      }
+    }
+    if (descended) continue;
+    bool changed = false;
+    while (st.sp > 0) {  // bvh.cpp:256-265
+      --st.sp;
+      const uint2 e = stack_read(st, st.sp);
+      if (__uint_as_float(e.y) < tmin) {
+        cur = load_node(sc.nodes, e.x);
+        changed = true;
+        break;
+      }
+    }
+    if (changed) continue;
+    if (hit >= 0) hit_point = ray.d * tmin + ray.o;
+    return hit;
+  }
+}
+
+// Any hit.  Q1: after a dead end the reference pops EVERYTHING and resumes at the
+// bottom-most entry; Q2: an early `return true` leaves its entries on the stack for the
+// next query of the same pixel.
+template <class CT>
+__device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
+  float tmp;
+  NodeRec cur = load_node(sc.nodes, 0);
+  ct.add(kNodeTests);
+  if (!aabb_intercepts(xyz(cur.lo), xyz(cur.hi), ray, tmp)) return false;
+  while (true) {
+    const uint32_t index = __float_as_uint(cur.lo.w), cl = __float_as_uint(cur.hi.w);
+    bool descended = false;
+    if (!(cl & P3D_BVH_LEAF)) {
+      const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
+      float l_t, r_t;
+      ct.add(kNodeTests, 2);
+      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t);
+      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t);
+      if (l_hit && r_hit) {
+        if (l_t < r_t) { cur = l; push(st, index + 1, r_t, ct); }
+        else           { cur = r; push(st, index, l_t, ct); }
+        descended = true;
+      } else if (l_hit) { cur = l; descended = true; }
+      else if (r_hit)   { cur = r; descended = true; }
+    } else {
+      const uint32_t n = cl & ~P3D_BVH_LEAF;
+      for (uint32_t s = index; s < index + n; ++s) {
+        const Geom g = load_geom(sc.bgeom, s);
+        float curr_t;
+        if (intercepts(g, ray, curr_t, ct)) return true;  // entries stay behind (Q2)
+      }
+    }
+    if (descended) continue;
+    if (st.sp > 0) {  // bvh.cpp:329-334: pop all, continue from the first-pushed entry
+      cur = load_node(sc.nodes, stack_read(st, 0).x);
+      st.sp = 0;
+      continue;
+    }
+    return false;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Brute force — main.cpp:116-124 (closest) and main.cpp:208-216 (any).  The closest-hit
+// loop works on the CALLER's ray (Object::intercepts takes Ray&), so the caller sees Q8.
+// ---------------------------------------------------------------------------
+template <class CT>
+__device__ int brute_closest(const DevScene& sc, RayS& ray, float& min_t, Geom& hit_geom, CT& ct) {
+  int min_obj = -1;
+  min_t = FLT_MAX;
+  for (uint32_t i = 0; i < sc.n_objs; ++i) {
+    const Geom g = load_geom(sc.ogeom, i);
+    float t;
+    if (intercepts(g, ray, t, ct) && t < min_t) {
+      min_obj = (int)i;
+      min_t = t;
+      hit_geom = g;
+    }
+  }
+  return min_obj;
+}
+template <class CT>
+__device__ bool brute_any(const DevScene& sc, RayS& ray, CT& ct) {
+  for (uint32_t i = 0; i < sc.n_objs; ++i) {
+    const Geom g = load_geom(sc.ogeom, i);
+    float t;
+    if (intercepts(g, ray, t, ct)) return true;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------
+// Uniform grid — grid.cpp:71-370 (3D-DDA).  t_next / dt are doubles as in the reference.
+// ---------------------------------------------------------------------------
+struct GridWalk {
+  int ix, iy, iz, ix_step, iy_step, iz_step, ix_stop, iy_stop, iz_stop;
+  double dtx, dty, dtz, tx_next, ty_next, tz_next;
+};
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+__device__ inline bool grid_init(const DevGrid& G, const RayS& ray, GridWalk& k) {  // grid.cpp:261-370
+  const F3 o = ray.o, dir = ray.d, mn = G.bmin, mx = G.bmax;
+  const int nx = G.nx, ny = G.ny, nz = G.nz;
+  float tx_min = (mn.x - o.x) / dir.x, ty_min = (mn.y - o.y) / dir.y, tz_min = (mn.z - o.z) / dir.z;
+  float tx_max = (mx.x - o.x) / dir.x, ty_max = (mx.y - o.y) / dir.y, tz_max = (mx.z - o.z) / dir.z;
+  if (tx_min > tx_max) { const float s = tx_max; tx_max = tx_min; tx_min = s; }
+  if (ty_min > ty_max) { const float s = ty_max; ty_max = ty_min; ty_min = s; }
+  if (tz_min > tz_max) { const float s = tz_max; tz_max = tz_min; tz_min = s; }
+  const float t0 = max3_ref(tx_min, ty_min, tz_min);
+  const float t1 = min3_ref(tx_max, ty_max, tz_max);
+  if (t0 > t1 || t1 < 0) return false;
+  k.dtx = (double)((tx_max - tx_min) / nx);
+  k.dty = (double)((ty_max - ty_min) / ny);
+  k.dtz = (double)((tz_max - tz_min) / nz);
+  F3 p = o;
+  if (!is_inside(mn, mx, o)) p = o + dir * t0;
+  k.ix = (int)clampd((double)((p.x - mn.x) * nx / (mx.x - mn.x)), 0, nx - 1);
+  k.iy = (int)clampd((double)((p.y - mn.y) * ny / (mx.y - mn.y)), 0, ny - 1);
+  k.iz = (int)clampd((double)((p.z - mn.z) * nz / (mx.z - mn.z)), 0, nz - 1);
+  if (dir.x > 0) { k.tx_next = tx_min + (k.ix + 1) * k.dtx; k.ix_step = 1; k.ix_stop = nx; }
+  else           { k.tx_next = tx_min + (nx - k.ix) * k.dtx; k.ix_step = -1; k.ix_stop = -1; }
+  if (dir.x == 0.0f) k.tx_next = FLT_MAX;
+  if (dir.y > 0) { k.ty_next = ty_min + (k.iy + 1) * k.dty; k.iy_step = 1; k.iy_stop = ny; }
+  else           { k.ty_next = ty_min + (ny - k.iy) * k.dty; k.iy_step = -1; k.iy_stop = -1; }
+  if (dir.y == 0.0f) k.ty_next = FLT_MAX;
+  if (dir.z > 0) { k.tz_next = tz_min + (k.iz + 1) * k.dtz; k.iz_step = 1; k.iz_stop = nz; }
+  else           { k.tz_next = tz_min + (nz - k.iz) * k.dtz; k.iz_step = -1; k.iz_stop = -1; }
+  if (dir.z == 0.0f) k.tz_next = FLT_MAX;
+  return true;
+}
+
+// advance one cell; returns false when the walk leaves the grid.  `limit` receives the
+// t_next of the axis about to be crossed (the acceptance bound of grid.cpp:108,123,137).
+__device__ __forceinline__ bool grid_step(GridWalk& k, double& limit) {
+  if (k.tx_next < k.ty_next && k.tx_next < k.tz_next) {
+    limit = k.tx_next; k.tx_next += k.dtx; k.ix += k.ix_step;
+    return k.ix != k.ix_stop;
+  } else if (k.ty_next < k.tz_next) {
+    limit = k.ty_next; k.ty_next += k.dty; k.iy += k.iy_step;
+    return k.iy != k.iy_stop;
+  } else {
+    limit = k.tz_next; k.tz_next += k.dtz; k.iz += k.iz_step;
+    return k.iz != k.iz_stop;
+  }
+}
+
+// grid.cpp:71-151: the caller's ray (Ray&) is tested and mutated; hit point = o + d*min_t
+template <class CT>
+__device__ int grid_closest(const DevScene& sc, RayS& ray, F3& hit_point, Geom& hit_geom, CT& ct) {
+  const DevGrid& G = sc.grid;
+  GridWalk k;
+  if (!grid_init(G, ray, k)) return -1;
+  int min_obj = -1;
+  float min_t = FLT_MAX;
+  while (true) {
+    const uint32_t c = (uint32_t)(k.ix + G.nx * k.iy + G.nx * G.ny * k.iz);
+    const uint32_t b = G.cell_start[c], e = G.cell_start[c + 1];
+    for (uint32_t i = b; i < e; ++i) {
+      const uint32_t obj = G.cell_items[i];
+      const Geom g = load_geom(sc.ogeom, obj);
+      float t;
+      if (intercepts(g, ray, t, ct) && t < min_t) {
+        min_t = t;
+        min_obj = (int)obj;
+        hit_geom = g;
+      }
+    }
+    double limit;
+    const bool more = grid_step(k, limit);
+    if (min_obj >= 0 && (double)min_t < limit) {
+      hit_point = ray.o + ray.d * min_t;
+      return min_obj;
+    }
+    if (!more) return -1;
+  }
+}
+// grid.cpp:154-208
+template <class CT>
+__device__ bool grid_any(const DevScene& sc, RayS& ray, CT& ct) {
+  const DevGrid& G = sc.grid;
+  GridWalk k;
+  if (!grid_init(G, ray, k)) return false;
+  while (true) {
+    const uint32_t c = (uint32_t)(k.ix + G.nx * k.iy + G.nx * G.ny * k.iz);
+    const uint32_t b = G.cell_start[c], e = G.cell_start[c + 1];
+    for (uint32_t i = b; i < e; ++i) {
+      const Geom g = load_geom(sc.ogeom, G.cell_items[i]);
+      float t;
+      if (intercepts(g, ray, t, ct)) return true;
+    }
+    double limit;
+    if (!grid_step(k, limit)) return false;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Closest hit as rayTracing / Radiance select it (main.cpp:103-125, 324-343, 449-469).
+// Returns the object id (-1 = miss); `P` is the reference's interceptNotPrecise
+// (main.cpp:164): o + d*min_t with the caller's (mutated) ray for accel None, the
+// traversal's hit point otherwise.
+// ---------------------------------------------------------------------------
+template <int ACCEL, class CT>
+__device__ __forceinline__ int closest_hit(const DevScene& sc, Stack& st, RayS& ray, F3& P, Geom& g, CT& ct) {
+  if (ACCEL == P3D_ACCEL_BVH) {
+    const int slot = bvh_closest(sc, st, ray, P, g, ct);
+    return slot < 0 ? -1 : (int)geom_object(g);
+  } else if (ACCEL == P3D_ACCEL_GRID) {
+    return grid_closest(sc, ray, P, g, ct);
+  } else {
+    float min_t;
+    const int obj = brute_closest(sc, ray, min_t, g, ct);
+    if (obj >= 0) P = ray.o + ray.d * min_t;
+    return obj;
+  }
+}
+// Shadow feeler (main.cpp:196-217).  Q6: with the grid, brute force runs as well.
+template <int ACCEL, class CT>
+__device__ __forceinline__ bool any_hit(const DevScene& sc, Stack& st, RayS& feeler, CT& ct) {
+  if (ACCEL == P3D_ACCEL_BVH) return bvh_any(sc, st, feeler, ct);
+  bool occluded = false;
+  if (ACCEL == P3D_ACCEL_GRID) occluded = grid_any(sc, feeler, ct);
+  const bool b = brute_any(sc, feeler, ct);
+  return occluded || b;
+}
+
+__device__ __forceinline__ F3 offset_intersection(F3 inter, F3 normal) { return inter + normal * .0001f; }  // main.cpp:82-84
+
+// ---------------------------------------------------------------------------
+// RNG: one PCG-XSH-RR 64/32 stream per (pixel, sample); same definition as the oracle's.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+struct Rng {
+  uint64_t state, inc;
+  __device__ __forceinline__ void seed_stream(uint64_t seed, uint32_t pixel, uint32_t sample) {
+    const uint64_t k = mix64(seed ^ mix64(((uint64_t)pixel << 32) | (uint64_t)sample));
+    inc = (mix64(k) << 1) | 1ull;
+    state = k * 6364136223846793005ull + inc;
+  }
+  __device__ __forceinline__ uint32_t next31() {
+    const uint64_t old = state;
+    state = old * 6364136223846793005ull + inc;
+    const uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
+    const uint32_t rot = (uint32_t)(old >> 59);
+    return ((xs >> rot) | (xs << ((0u - rot) & 31u))) >> 1;
+  }
+  // maths.h:67-70 with RAND_MAX = 2^31-1 ((float)RAND_MAX == 2^31); can return exactly 1.0f
+  __device__ __forceinline__ float rand_float() { return (float)next31() / 2147483648.0f; }
+  // main.cpp:75-77
+  __device__ __forceinline__ double erand48() { return (double)next31() / 2147483647.0; }
+};
+
+// camera.h:65-82
+__device__ __forceinline__ void primary_ray(const DevCamera& c, float px, float py, F3& o, F3& d) {
+  const float psx = c.w * (px / c.res_x - 0.5f);
+  const float psy = c.h * (py / c.res_y - 0.5f);
+  const float psz = -c.plane_dist;
+  d = normalized((c.u * psx + c.v * psy) + c.n * psz);
+  o = c.eye;
+}
+// camera.h:84-115
+__device__ __forceinline__ void primary_ray_lens(const DevCamera& c, float lx, float ly, float px, float py, F3& o,
+                                                 F3& d) {
+  const float psx = c.w * (px / c.res_x - 0.5f);
+  const float psy = c.h * (py / c.res_y - 0.5f);
+  const float lsx = lx * c.aperture, lsy = ly * c.aperture;
+  const float qx = psx * c.focal_ratio, qy = psy * c.focal_ratio;
+  d = normalized((c.u * (qx - lsx) + c.v * (qy - lsy)) + c.n * -(c.focal_ratio * c.plane_dist));
+  o = (c.eye + c.u * lsx) + c.v * lsy;
+}
+
+__device__ __forceinline__ uint8_t u8fromfloat(float x) {  // maths.h:81-86
+  const float s = x * 255.99f;
+  return s >= 255.0f ? (uint8_t)255 : (uint8_t)s;
+}
+
+}  // namespace p3d

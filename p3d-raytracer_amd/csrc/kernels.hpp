@@ -1,0 +1,346 @@
+// kernels.hpp — the HIP kernels of the hot path (gfx950).
+//
+//   whitted_kernel : primary ray -> closest hit -> Blinn-Phong with shadow feelers ->
+//                    reflect / refract chain with per-level clamp      (main.cpp:92-309 + 753-820)
+//   pt_kernel      : the smallpt-style Radiance loop as a persistent per-lane bounce loop
+//                    (main.cpp:313-516 + 758-800)
+//   trace_kernel   : batched closest / any-hit queries (bvh.cpp:198-340, grid.cpp:71-208,
+//                    main.cpp:116-124,208-216)
+//
+// One workgroup = one wavefront = an 8x8 pixel block.  See device_core.hpp for the
+// traversal conventions and DESIGN.md for the kernel-by-kernel roofline discussion.
+#pragma once
+
+#include "device_core.hpp"
+#include "p3d.h"
+
+namespace p3d {
+
+struct RenderParams {
+  DevScene sc;
+  const float4* blob;   // all float4 scene arrays, contiguous (for the LDS staging copy)
+  uint32_t blob_f4;     // size of blob in float4
+  // byte offsets (in float4) of the arrays inside blob, same order as DevScene
+  uint32_t off_nodes, off_bgeom, off_ogeom, off_normals, off_mats, off_lights;
+  // options (p3d_config)
+  int32_t max_depth;
+  uint32_t spp_sqrt, antialiasing, depth_of_field, sample_disk, soft_shadows, sample_mode;
+  float light_side, gamma;
+  uint64_t seed;
+  // tile
+  int32_t x0, y0, w, h, stripe_h, stripe_stride;
+  uint32_t tiles_x, tiles_y, tiles_per_xcd;
+  // outputs (device memory, any may be null)
+  float* rgb;
+  int32_t* hit_id;
+  uint8_t* rgb8;
+  // scratch
+  float4* levels;          // Whitted per-level records {local colour, child weight}, [level][thread]
+  uint32_t level_stride;   // threads in this launch
+  unsigned long long* stats;  // kNumStats counters
+  uint2* spill;               // node-stack overflow area, [entry - stack_cap][thread]
+  int32_t stack_cap;          // node-stack entries per lane held in LDS
+  uint32_t lds_scene_f4;      // float4s reserved for the staged scene (0 when not staged)
+};
+
+// LDS map of one workgroup:  [ staged scene (lds_scene_f4 float4) | node stack (cap * 64 * 8 B) | pending (PT) ]
+template <bool LDS>
+__device__ __forceinline__ void stage_scene(DevScene& sc, const RenderParams& P, float4* smem) {
+  if (LDS) {
+    for (uint32_t i = threadIdx.x; i < P.blob_f4; i += kBlock) smem[i] = P.blob[i];
+    __syncthreads();
+    sc.nodes = smem + P.off_nodes;
+    sc.bgeom = smem + P.off_bgeom;
+    sc.ogeom = smem + P.off_ogeom;
+    sc.normals = smem + P.off_normals;
+    sc.mats = smem + P.off_mats;
+    sc.lights = smem + P.off_lights;
+  }
+}
+
+// XCD-aware block -> tile map: workgroups are dealt round-robin over the 8 XCDs, so blocks
+// b, b+8, b+16, ... share an L2.  Give each XCD one contiguous band of 8x8 tiles, so the
+// BVH nodes a band touches stay in that XCD's 4 MiB L2 (matters for the 8.8 MB scene).
+__device__ __forceinline__ bool tile_of_block(const RenderParams& P, uint32_t& tx, uint32_t& ty) {
+  const uint32_t b = blockIdx.x;
+  const uint32_t tile = (b & 7u) * P.tiles_per_xcd + (b >> 3);
+  if ((b >> 3) >= P.tiles_per_xcd || tile >= P.tiles_x * P.tiles_y) return false;
+  tx = tile % P.tiles_x;
+  ty = tile / P.tiles_x;
+  return true;
+}
+
+template <bool STATS>
+__device__ __forceinline__ void flush_stats(Counters<STATS>&, unsigned long long*) {}
+template <>
+__device__ __forceinline__ void flush_stats<true>(Counters<true>& ct, unsigned long long* out) {
+  for (int s = 0; s < kNumStats; ++s) {
+    uint32_t v = ct.c[s];
+    if (s == kMaxStack) {
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = __shfl_xor(v, o, 64);
+        v = other > v ? other : v;
+      }
+      if ((threadIdx.x & 63) == 0) atomicMax(&out[s], (unsigned long long)v);
+    } else {
+      unsigned long long w = v;
+      for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+      if ((threadIdx.x & 63) == 0 && w) atomicAdd(&out[s], w);
+    }
+  }
+}
+
+// Pixel sample of main.cpp:758-787: sub-pixel position (jitter / tent), optional lens sample.
+__device__ __forceinline__ void make_primary(const RenderParams& P, const DevCamera& cam, int x, int y, int i, int j,
+                                             Rng& rng, F3& o, F3& d) {
+  const int SPP = (int)P.spp_sqrt;
+  float px, py;
+  if (!P.antialiasing) {  // main.cpp:805-808
+    px = (float)(x + 0.5);
+    py = (float)(y + 0.5);
+    primary_ray(cam, px, py, o, d);
+    return;
+  }
+  if (P.sample_mode == P3D_SAMPLE_JITTER) {  // main.cpp:763-766
+    px = x + (i + rng.rand_float()) / SPP;
+    py = y + (j + rng.rand_float()) / SPP;
+  } else {  // tent, main.cpp:767-773
+    const double r1 = 2 * rng.erand48(), dx = r1 < 1 ? sqrt(r1) - 1 : 1 - sqrt(2 - r1);
+    const double r2 = 2 * rng.erand48(), dy = r2 < 1 ? sqrt(r2) - 1 : 1 - sqrt(2 - r2);
+    px = (float)(x + (0.5 + dx) / SPP);
+    py = (float)(y + (0.5 + dy) / SPP);
+  }
+  if (P.depth_of_field) {  // main.cpp:776-784
+    float lx, ly;
+    if (P.sample_disk) {  // sampler.cpp:5-11; argument order as g++ evaluates it: y first
+      do {
+        const float b = rng.rand_float();
+        const float a = rng.rand_float();
+        lx = a * 2 - 1.0f;
+        ly = b * 2 - 1.0f;
+      } while (lx * lx + ly * ly + 0.0f * 0.0f >= 1.0f);
+    } else {
+      lx = (i + rng.rand_float()) / SPP;
+      ly = (j + rng.rand_float()) / SPP;
+    }
+    primary_ray_lens(cam, lx, ly, px, py, o, d);
+  } else {
+    primary_ray(cam, px, py, o, d);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Whitted megakernel
+// ---------------------------------------------------------------------------
+template <int ACCEL, bool LDS, bool STATS>
+__global__ void __launch_bounds__(kBlock) whitted_kernel(const RenderParams P) {
+  extern __shared__ float4 smem[];
+  uint32_t tx, ty;
+  if (!tile_of_block(P, tx, ty)) return;
+  DevScene sc = P.sc;
+  stage_scene<LDS>(sc, P, smem);
+
+  const uint32_t lane = threadIdx.x;
+  const int c = (int)(tx * 8 + (lane & 7)), r = (int)(ty * 8 + (lane >> 3));
+  Counters<STATS> ct;
+  if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
+  Stack st;
+  st.base = reinterpret_cast<uint2*>(smem + P.lds_scene_f4) + lane;
+  st.spill = P.spill + (blockIdx.x * kBlock + lane);
+  st.spill_stride = P.level_stride;
+  st.sp = 0;
+  st.cap = P.stack_cap;
+
+  const bool active = c < P.w && r < P.h;
+  if (active) {
+    const int sh = P.stripe_h > 0 ? P.stripe_h : 1, ss = P.stripe_h > 0 ? P.stripe_stride : 1;
+    const int x = P.x0 + c;
+    const int y = P.y0 + (r / sh) * sh * ss + (r % sh);
+    const uint32_t gid = blockIdx.x * kBlock + lane;
+    const int SPP = P.antialiasing ? (int)P.spp_sqrt : 1;
+    ct.add(kPixels);
+
+    F3 color = f3(0, 0, 0);
+    int first_hit = -1;
+    Rng rng;
+    for (int si = 0; si < SPP; ++si) {
+      for (int sj = 0; sj < SPP; ++sj) {
+        rng.seed_stream(P.seed, (uint32_t)(y * sc.cam.res_x + x), (uint32_t)(si * SPP + sj));
+        st.sp = 0;  // hit_stack starts empty at every primary sample (DESIGN.md "Sequential state")
+        F3 o, d;
+        make_primary(P, sc.cam, x, y, si, sj, rng, o, d);
+        RayS ray;
+        ray_set(ray, o, d);
+        ct.add(kRaysPrimary);
+
+        int depth = P.max_depth;
+        float ior_1 = 1.0f;
+        bool inside = false;
+        int level = 0;
+        F3 result;
+        while (true) {  // the reflect / refract chain of main.cpp:92-309 (a chain, not a tree: Q3)
+          F3 Pn;
+          Geom g;
+          const int obj = closest_hit<ACCEL>(sc, st, ray, Pn, g, ct);
+          if (level == 0 && si == 0 && sj == 0) first_hit = obj;
+          if (obj < 0) {  // main.cpp:144-147, SKYBOX false
+            result = sc.bg;
+            break;
+          }
+          ct.add(kShadedHits);
+          const uint32_t m = geom_material(g);
+          const float4 m0 = sc.mats[4 * m], m1 = sc.mats[4 * m + 1], m2 = sc.mats[4 * m + 2];
+          const F3 intercept = offset_intersection(Pn, get_normal(g, sc.normals, Pn));  // main.cpp:165
+          F3 norm = get_normal(g, sc.normals, intercept);                               // main.cpp:167
+          F3 diff = f3(0, 0, 0), spec = f3(0, 0, 0);
+          if (!inside) {  // main.cpp:172-227
+            for (uint32_t li = 0; li < sc.n_lights; ++li) {
+              const float4 l0 = sc.lights[2 * li], l1 = sc.lights[2 * li + 1];
+              F3 lpos = xyz(l0);
+              if (P.antialiasing && P.soft_shadows) {  // main.cpp:180-186 (g++ draws y first)
+                const float jy = rng.rand_float();
+                const float jx = rng.rand_float();
+                lpos = f3(l0.x + P.light_side * (si + jx) / SPP, l0.y + P.light_side * (sj + jy) / SPP, l0.z);
+              }
+              const F3 l_dir = normalized(lpos - intercept);
+              RayS feeler;
+              ray_set(feeler, intercept, l_dir);
+              ct.add(kRaysShadow);
+              const bool shadowed = any_hit<ACCEL>(sc, st, feeler, ct);
+              const F3 blinn = normalized((l_dir + get_direction(ray) * -1.0f) / 2);
+              if (!shadowed) {  // main.cpp:222-225: max() and pow() evaluate in double
+                const float nl = dot(norm, l_dir);
+                const float bn = dot(blinn, norm);
+                const float kd = (0.0f > nl) ? 0.0f : nl;
+                const float kb = (0.0f > bn) ? 0.0f : bn;
+                diff = diff + (xyz(l1) * xyz(m0)) * kd;
+                spec = spec + (xyz(l1) * xyz(m1)) * (float)pow((double)kb, (double)m2.x);
+              }
+            }
+          }
+          const F3 col = diff * m0.w + spec * m1.w;  // main.cpp:232
+          if (depth <= 0) {
+            result = clamp01(col);
+            break;
+          }
+          norm = !inside ? norm : norm * -1.0f;  // main.cpp:238
+          const F3 v = get_direction(ray) * -1.0f;
+          const F3 vn = norm * dot(v, norm);
+          F3 vt = vn - v;
+          bool have_child = false;
+          float weight = 0.0f;
+          RayS child;
+          bool child_inside = inside;
+          float child_ior = ior_1;
+          if (m2.y == 0) {          // opaque: Kr = Ks (main.cpp:250)
+            if (m2.w > 0) {         // reflective (main.cpp:290-300)
+              // g++ evaluates the right operand of `+` first; both calls re-normalise ray.d
+              const F3 b = get_direction(ray);
+              const F3 a = norm * dot(get_direction(ray) * -1.0f, norm) * 2;
+              ray_set(child, intercept, a + b);
+              weight = m1.w;
+              have_child = true;
+              ct.add(kRaysReflect);
+            }
+          } else {                  // transmissive (main.cpp:252-283): Kr = 1/2*(Rs+Rp) == 0 (Q3)
+            const float n = !inside ? ior_1 / m2.z : ior_1 / 1;
+            const float sinOt = n * length(vt);
+            const float insqrt = (float)(1 - (double)sinOt * (double)sinOt);  // 1 - pow(sinOt,2) in double
+            if (insqrt >= 0) {
+              const float cosOt = sqrtf(insqrt);
+              F3 refractDir = normalized(vt) * sinOt + norm * (-cosOt);
+              refractDir = normalized(refractDir);
+              ray_set(child, offset_intersection(Pn, refractDir), refractDir);  // main.cpp:267
+              child_ior = !inside ? m2.z : 1.0f;
+              child_inside = !inside;
+              weight = 1.0f;  // (1 - Kr) with Kr == 0; the zero-weight reflection ray is not traced
+              have_child = true;
+              ct.add(kRaysRefract);
+            }
+          }
+          if (!have_child) {
+            result = clamp01(col);
+            break;
+          }
+          P.levels[(size_t)level * P.level_stride + gid] = make_float4(col.x, col.y, col.z, weight);
+          ++level;
+          --depth;
+          ray = child;
+          ior_1 = child_ior;
+          inside = child_inside;
+        }
+        // fold the chain bottom-up with the per-level clamp (main.cpp:305-307, Q4)
+        while (level > 0) {
+          --level;
+          const float4 rec = P.levels[(size_t)level * P.level_stride + gid];
+          result = clamp01(f3(rec.x, rec.y, rec.z) + result * rec.w);
+        }
+        color = color + result;
+      }
+    }
+    if (P.antialiasing) color = color / (float)(SPP * SPP);  // main.cpp:800
+
+    const size_t k = (size_t)r * P.w + c;
+    if (P.rgb) {
+      P.rgb[3 * k] = color.x; P.rgb[3 * k + 1] = color.y; P.rgb[3 * k + 2] = color.z;
+    }
+    if (P.hit_id) P.hit_id[k] = first_hit;
+    if (P.rgb8) {  // main.cpp:814-820
+      F3 gc = color;
+      if (P.gamma != 1.0f) {
+        const double ig = (double)(1 / P.gamma);
+        gc = f3((float)pow((double)color.x, ig), (float)pow((double)color.y, ig), (float)pow((double)color.z, ig));
+      }
+      P.rgb8[3 * k] = u8fromfloat(gc.x); P.rgb8[3 * k + 1] = u8fromfloat(gc.y); P.rgb8[3 * k + 2] = u8fromfloat(gc.z);
+    }
+  }
+  if (STATS) flush_stats<STATS>(ct, P.stats);
+}
+
+// ---------------------------------------------------------------------------
+// Batched queries (unit-level parity of the traversal back ends)
+// ---------------------------------------------------------------------------
+struct TraceParams {
+  DevScene sc;
+  uint32_t n;
+  const float* origin;
+  const float* direction;
+  int32_t* hit_id;
+  float* t;
+  float* hit_point;
+  uint8_t* occluded;
+  uint2* spill;
+  uint32_t spill_stride;
+  int32_t stack_cap;
+};
+
+template <int ACCEL, bool ANY>
+__global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P) {
+  extern __shared__ float4 smem[];
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  Stack st;
+  st.base = reinterpret_cast<uint2*>(smem) + threadIdx.x;
+  st.spill = P.spill + i;
+  st.spill_stride = P.spill_stride;
+  st.sp = 0;
+  st.cap = P.stack_cap;
+  if (i >= P.n) return;
+  Counters<false> ct;
+  RayS ray;
+  ray_set(ray, f3(P.origin[3 * i], P.origin[3 * i + 1], P.origin[3 * i + 2]),
+          f3(P.direction[3 * i], P.direction[3 * i + 1], P.direction[3 * i + 2]));
+  if (ANY) {
+    P.occluded[i] = any_hit<ACCEL>(P.sc, st, ray, ct) ? 1 : 0;
+  } else {
+    F3 hp = f3(0, 0, 0);
+    Geom g;
+    const int obj = closest_hit<ACCEL>(P.sc, st, ray, hp, g, ct);
+    P.hit_id[i] = obj;
+    if (obj < 0) hp = f3(0, 0, 0);
+    if (P.hit_point) {
+      P.hit_point[3 * i] = hp.x; P.hit_point[3 * i + 1] = hp.y; P.hit_point[3 * i + 2] = hp.z;
+    }
+  }
+}
+
+}  // namespace p3d

@@ -1,0 +1,467 @@
+// p3d_capi.hip — device half of include/p3d.h: scene upload, kernel dispatch, batched
+// queries.  There is no CPU fallback anywhere in this file: every entry point needs a
+// HIP device and fails with P3D_ERR_NO_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../host/p3d_error.hpp"
+#include "kernels.hpp"
+#include "p3d.h"
+#include "pt_kernel.hpp"
+
+using namespace p3d;
+
+namespace {
+
+#define P3D_HIP(call)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(P3D_ERR_NO_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+constexpr uint32_t kLdsSceneLimitBytes = 16 * 1024;  // stage the scene in LDS up to this size
+constexpr uint32_t kMaxLaunchThreads = 1u << 21;     // bounds the per-launch scratch arrays
+
+inline F3 to_f3(const float v[3]) { return F3{v[0], v[1], v[2]}; }
+
+struct Scratch {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return P3D_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    P3D_HIP(hipMalloc(&p, need));
+    bytes = need;
+    return P3D_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+}  // namespace
+
+struct p3d_scene {
+  int device = 0;
+  float4* d_blob = nullptr;
+  uint32_t blob_f4 = 0;
+  uint32_t off_nodes = 0, off_bgeom = 0, off_ogeom = 0, off_normals = 0, off_mats = 0, off_lights = 0;
+  uint32_t* d_cell_start = nullptr;
+  uint32_t* d_cell_items = nullptr;
+  uint32_t* d_emitters = nullptr;
+  DevScene dev{};
+  bool has_bvh = false, has_grid = false;
+  uint32_t bvh_max_depth = 0;
+  Scratch levels, spill, out_rgb, out_hit, out_rgb8, q_in, q_out;
+  unsigned long long* d_stats = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" {
+
+int p3d_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  return n;
+}
+
+void p3d_scene_destroy(p3d_scene* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->d_blob) (void)hipFree(s->d_blob);
+  if (s->d_cell_start) (void)hipFree(s->d_cell_start);
+  if (s->d_cell_items) (void)hipFree(s->d_cell_items);
+  if (s->d_emitters) (void)hipFree(s->d_emitters);
+  if (s->d_stats) (void)hipFree(s->d_stats);
+  s->levels.release(); s->spill.release(); s->out_rgb.release(); s->out_hit.release();
+  s->out_rgb8.release(); s->q_in.release(); s->q_out.release();
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  delete s;
+}
+
+int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
+  if (!d || !out) return fail(P3D_ERR_INVALID, "p3d_scene_create: null argument");
+  if (d->abi_version != P3D_ABI_VERSION) return fail(P3D_ERR_INVALID, "p3d_scene_create: ABI version mismatch");
+  if ((d->n_prims && !d->prims) || (d->n_materials && !d->materials) || (d->n_lights && !d->lights))
+    return fail(P3D_ERR_INVALID, "p3d_scene_create: null array with non-zero count");
+  for (uint32_t i = 0; i < d->n_prims; ++i) {
+    if (d->prims[i].material >= d->n_materials) return fail(P3D_ERR_INVALID, "p3d_scene_create: material index out of range");
+    if (d->prims[i].type > P3D_PRIM_PLANE) return fail(P3D_ERR_INVALID, "p3d_scene_create: unknown primitive type");
+  }
+  if (d->n_bvh_nodes) {  // every index a lane may follow is checked here, not in the kernel
+    if (!d->bvh_nodes || (d->n_bvh_prim_index && !d->bvh_prim_index) || d->n_bvh_prim_index != d->n_prims)
+      return fail(P3D_ERR_INVALID, "p3d_scene_create: inconsistent BVH arrays");
+    for (uint32_t i = 0; i < d->n_bvh_nodes; ++i) {
+      const p3d_bvh_node& n = d->bvh_nodes[i];
+      if (n.count_leaf & P3D_BVH_LEAF) {
+        const uint64_t cnt = n.count_leaf & ~P3D_BVH_LEAF;
+        if ((uint64_t)n.index + cnt > d->n_bvh_prim_index) return fail(P3D_ERR_INVALID, "p3d_scene_create: BVH leaf range out of bounds");
+      } else if ((uint64_t)n.index + 1 >= d->n_bvh_nodes || n.index <= i) {
+        return fail(P3D_ERR_INVALID, "p3d_scene_create: BVH child index out of bounds");
+      }
+    }
+    for (uint32_t i = 0; i < d->n_bvh_prim_index; ++i)
+      if (d->bvh_prim_index[i] >= d->n_prims) return fail(P3D_ERR_INVALID, "p3d_scene_create: BVH object index out of bounds");
+    if (d->bvh_max_depth == 0 || d->bvh_max_depth > 4096) return fail(P3D_ERR_INVALID, "p3d_scene_create: bad bvh_max_depth");
+  }
+  if (d->has_grid) {
+    const p3d_grid_desc& g = d->grid;
+    if (g.nx <= 0 || g.ny <= 0 || g.nz <= 0 || (uint64_t)g.nx * g.ny * g.nz != g.n_cells || !g.cell_start ||
+        (g.n_items && !g.cell_items) || g.cell_start[g.n_cells] != g.n_items)
+      return fail(P3D_ERR_INVALID, "p3d_scene_create: inconsistent grid arrays");
+    for (uint32_t c = 0; c < g.n_cells; ++c)
+      if (g.cell_start[c] > g.cell_start[c + 1]) return fail(P3D_ERR_INVALID, "p3d_scene_create: grid cell_start not monotone");
+    for (uint32_t i = 0; i < g.n_items; ++i)
+      if (g.cell_items[i] >= d->n_prims) return fail(P3D_ERR_INVALID, "p3d_scene_create: grid object index out of bounds");
+  }
+  int ndev = 0;
+  P3D_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(P3D_ERR_NO_DEVICE, "p3d_scene_create: no such HIP device");
+  P3D_HIP(hipSetDevice(device));
+
+  // ---- build the float4 blob: nodes | bgeom | ogeom | normals | mats | lights ----
+  auto geom_of = [&](uint32_t obj, float4 dst[3]) {
+    const p3d_prim& p = d->prims[obj];
+    dst[0] = make_float4(p.v[0], p.v[1], p.v[2], p.v[3]);
+    dst[1] = make_float4(p.v[4], p.v[5], p.v[6], p.v[7]);
+    const uint32_t tm = p.type | (p.material << 8);
+    float tmf, objf;
+    std::memcpy(&tmf, &tm, 4);
+    std::memcpy(&objf, &obj, 4);
+    dst[2] = make_float4(p.v[8], tmf, objf, 0.f);
+  };
+  std::vector<float4> blob;
+  auto s = std::unique_ptr<p3d_scene>(new p3d_scene());
+  s->device = device;
+  s->off_nodes = (uint32_t)blob.size();
+  for (uint32_t i = 0; i < d->n_bvh_nodes; ++i) {
+    const p3d_bvh_node& n = d->bvh_nodes[i];
+    float idx, cl;
+    std::memcpy(&idx, &n.index, 4);
+    std::memcpy(&cl, &n.count_leaf, 4);
+    blob.push_back(make_float4(n.bmin[0], n.bmin[1], n.bmin[2], idx));
+    blob.push_back(make_float4(n.bmax[0], n.bmax[1], n.bmax[2], cl));
+  }
+  s->off_bgeom = (uint32_t)blob.size();
+  for (uint32_t i = 0; i < d->n_bvh_prim_index; ++i) {
+    float4 g[3];
+    geom_of(d->bvh_prim_index[i], g);
+    blob.insert(blob.end(), g, g + 3);
+  }
+  s->off_ogeom = (uint32_t)blob.size();
+  for (uint32_t i = 0; i < d->n_prims; ++i) {
+    float4 g[3];
+    geom_of(i, g);
+    blob.insert(blob.end(), g, g + 3);
+  }
+  s->off_normals = (uint32_t)blob.size();
+  for (uint32_t i = 0; i < d->n_prims; ++i) blob.push_back(make_float4(d->prims[i].n[0], d->prims[i].n[1], d->prims[i].n[2], 0.f));
+  s->off_mats = (uint32_t)blob.size();
+  for (uint32_t i = 0; i < d->n_materials; ++i) {
+    const p3d_material& m = d->materials[i];
+    blob.push_back(make_float4(m.diff_color[0], m.diff_color[1], m.diff_color[2], m.diffuse));
+    blob.push_back(make_float4(m.spec_color[0], m.spec_color[1], m.spec_color[2], m.specular));
+    blob.push_back(make_float4(m.shine, m.transmittance, m.refr_index, m.reflection));
+    blob.push_back(make_float4(m.emission[0], m.emission[1], m.emission[2], 0.f));
+  }
+  s->off_lights = (uint32_t)blob.size();
+  for (uint32_t i = 0; i < d->n_lights; ++i) {
+    const p3d_light& l = d->lights[i];
+    blob.push_back(make_float4(l.position[0], l.position[1], l.position[2], 0.f));
+    blob.push_back(make_float4(l.color[0], l.color[1], l.color[2], 0.f));
+  }
+  if (blob.empty()) blob.push_back(make_float4(0, 0, 0, 0));
+  s->blob_f4 = (uint32_t)blob.size();
+  P3D_HIP(hipMalloc((void**)&s->d_blob, blob.size() * sizeof(float4)));
+  P3D_HIP(hipMemcpy(s->d_blob, blob.data(), blob.size() * sizeof(float4), hipMemcpyHostToDevice));
+
+  // emissive spheres in object order: the light loop of Radiance (main.cpp:407-415)
+  std::vector<uint32_t> emitters;
+  for (uint32_t i = 0; i < d->n_prims; ++i) {
+    const p3d_material& m = d->materials[d->prims[i].material];
+    if (m.emission[0] + m.emission[1] + m.emission[2] > 0 && d->prims[i].type == P3D_PRIM_SPHERE) emitters.push_back(i);
+  }
+  if (!emitters.empty()) {
+    P3D_HIP(hipMalloc((void**)&s->d_emitters, emitters.size() * 4));
+    P3D_HIP(hipMemcpy(s->d_emitters, emitters.data(), emitters.size() * 4, hipMemcpyHostToDevice));
+  }
+  DevScene& v = s->dev;
+  v.nodes = s->d_blob + s->off_nodes;
+  v.bgeom = s->d_blob + s->off_bgeom;
+  v.ogeom = s->d_blob + s->off_ogeom;
+  v.normals = s->d_blob + s->off_normals;
+  v.mats = s->d_blob + s->off_mats;
+  v.lights = s->d_blob + s->off_lights;
+  v.emitters = s->d_emitters;
+  v.n_nodes = d->n_bvh_nodes;
+  v.n_slots = d->n_bvh_prim_index;
+  v.n_objs = d->n_prims;
+  v.n_mats = d->n_materials;
+  v.n_lights = d->n_lights;
+  v.n_emitters = (uint32_t)emitters.size();
+  const p3d_camera& c = d->camera;
+  v.cam.eye = to_f3(c.eye); v.cam.u = to_f3(c.u); v.cam.v = to_f3(c.v); v.cam.n = to_f3(c.n);
+  v.cam.w = c.w; v.cam.h = c.h; v.cam.plane_dist = c.plane_dist; v.cam.focal_ratio = c.focal_ratio;
+  v.cam.aperture = c.aperture; v.cam.res_x = c.res_x; v.cam.res_y = c.res_y;
+  v.bg = to_f3(d->background);
+  s->has_bvh = d->n_bvh_nodes > 0;
+  s->bvh_max_depth = d->bvh_max_depth;
+  if (d->has_grid) {
+    const p3d_grid_desc& g = d->grid;
+    P3D_HIP(hipMalloc((void**)&s->d_cell_start, (size_t)(g.n_cells + 1) * 4));
+    P3D_HIP(hipMemcpy(s->d_cell_start, g.cell_start, (size_t)(g.n_cells + 1) * 4, hipMemcpyHostToDevice));
+    P3D_HIP(hipMalloc((void**)&s->d_cell_items, (size_t)std::max<uint32_t>(g.n_items, 1) * 4));
+    if (g.n_items) P3D_HIP(hipMemcpy(s->d_cell_items, g.cell_items, (size_t)g.n_items * 4, hipMemcpyHostToDevice));
+    v.grid.bmin = to_f3(g.bmin); v.grid.bmax = to_f3(g.bmax);
+    v.grid.nx = g.nx; v.grid.ny = g.ny; v.grid.nz = g.nz;
+    v.grid.cell_start = s->d_cell_start; v.grid.cell_items = s->d_cell_items;
+    s->has_grid = true;
+  }
+  P3D_HIP(hipMalloc((void**)&s->d_stats, kNumStats * sizeof(unsigned long long)));
+  P3D_HIP(hipEventCreate(&s->ev0));
+  P3D_HIP(hipEventCreate(&s->ev1));
+  *out = s.release();
+  return P3D_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------
+namespace {
+
+template <int ACCEL, bool LDS, bool STATS>
+hipError_t launch_one(bool pt, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+  if (pt) hipLaunchKernelGGL((pt_kernel<ACCEL, LDS, STATS>), dim3(blocks), dim3(kBlock), lds, st, P);
+  else hipLaunchKernelGGL((whitted_kernel<ACCEL, LDS, STATS>), dim3(blocks), dim3(kBlock), lds, st, P);
+  return hipGetLastError();
+}
+template <int ACCEL>
+hipError_t launch_accel(bool pt, bool lds_scene, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+  if (lds_scene) return stats ? launch_one<ACCEL, true, true>(pt, P, blocks, lds, st) : launch_one<ACCEL, true, false>(pt, P, blocks, lds, st);
+  return stats ? launch_one<ACCEL, false, true>(pt, P, blocks, lds, st) : launch_one<ACCEL, false, false>(pt, P, blocks, lds, st);
+}
+
+int check_accel(const p3d_scene* s, uint32_t accel) {
+  if (accel == P3D_ACCEL_BVH && !s->has_bvh) return fail(P3D_ERR_INVALID, "accel = Bvh but the scene was created without BVH arrays");
+  if (accel == P3D_ACCEL_GRID && !s->has_grid) return fail(P3D_ERR_INVALID, "accel = UGrid but the scene was created without a grid");
+  if (accel > P3D_ACCEL_BVH) return fail(P3D_ERR_INVALID, "unknown accel");
+  return P3D_OK;
+}
+
+// worst-case node-stack height: each shadow feeler that returns `true` may leave up to
+// depth-1 entries behind (Q2) and the next closest-hit query adds depth-1 more
+uint32_t stack_bound(const p3d_scene* s, uint32_t accel, bool whitted) {
+  if (accel != P3D_ACCEL_BVH) return 1;
+  const uint32_t per = s->bvh_max_depth > 1 ? s->bvh_max_depth - 1 : 1;
+  return whitted ? (s->dev.n_lights + 1) * per : per;
+}
+
+}  // namespace
+
+extern "C" {
+
+int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* tile, float* d_rgb, int32_t* d_hit,
+                           uint8_t* d_rgb8, void* hip_stream, p3d_stats* stats) {
+  if (!s || !cfg || !tile) return fail(P3D_ERR_INVALID, "p3d_render_tile_device: null argument");
+  if (int rc = check_accel(s, cfg->accel)) return rc;
+  const DevCamera& cam = s->dev.cam;
+  if (cam.res_x <= 0 || cam.res_y <= 0) return fail(P3D_ERR_INVALID, "scene has no camera");
+  const int sh = tile->stripe_h > 0 ? tile->stripe_h : 1, ss = tile->stripe_h > 0 ? tile->stripe_stride : 1;
+  if (tile->w <= 0 || tile->h <= 0 || tile->x0 < 0 || tile->y0 < 0 || ss < 1 || tile->x0 + tile->w > cam.res_x)
+    return fail(P3D_ERR_INVALID, "tile outside the image");
+  {
+    const int last = tile->h - 1;
+    const long long ylast = (long long)tile->y0 + (long long)(last / sh) * sh * ss + (last % sh);
+    if (ylast >= cam.res_y) return fail(P3D_ERR_INVALID, "tile rows outside the image");
+  }
+  if (cfg->integrator > P3D_PATHTRACE || cfg->sample_mode > P3D_SAMPLE_TENT) return fail(P3D_ERR_INVALID, "bad integrator / sample_mode");
+  if (cfg->max_depth < 0 || cfg->max_depth > 1024) return fail(P3D_ERR_INVALID, "max_depth out of range");
+  if (cfg->antialiasing && (cfg->spp_sqrt == 0 || cfg->spp_sqrt > 1024)) return fail(P3D_ERR_INVALID, "spp_sqrt out of range");
+  if (cfg->soft_shadows && !cfg->antialiasing)
+    ;  // light replication (main.cpp:725-745) is a host-side scene edit: p3d_host_scene_replicate_lights
+  if (cfg->accel == P3D_ACCEL_GRID && s->dev.n_objs == 0) return fail(P3D_ERR_UNSUPPORTED, "grid over an empty scene");
+  P3D_HIP(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+
+  // main.cpp:804-812: without ANTIALIASING the frame loop always calls rayTracing
+  const bool pt = cfg->integrator == P3D_PATHTRACE && cfg->antialiasing;
+  const bool lds_scene = (size_t)s->blob_f4 * sizeof(float4) <= kLdsSceneLimitBytes;
+  const uint32_t bound = stack_bound(s, cfg->accel, !pt);
+  const uint32_t depth_cap = std::min<uint32_t>(std::max<uint32_t>(s->bvh_max_depth + 3, 8), 24);
+  const uint32_t cap = cfg->accel == P3D_ACCEL_BVH ? std::min(bound, depth_cap) : 1;
+  const uint32_t spill_entries = bound > cap ? bound - cap : 0;
+  const bool want_counts = stats && cfg->collect_stats;
+
+  RenderParams P{};
+  P.sc = s->dev;
+  P.blob = s->d_blob; P.blob_f4 = s->blob_f4;
+  P.off_nodes = s->off_nodes; P.off_bgeom = s->off_bgeom; P.off_ogeom = s->off_ogeom;
+  P.off_normals = s->off_normals; P.off_mats = s->off_mats; P.off_lights = s->off_lights;
+  P.max_depth = cfg->max_depth; P.spp_sqrt = cfg->spp_sqrt; P.antialiasing = cfg->antialiasing;
+  P.depth_of_field = cfg->depth_of_field; P.sample_disk = cfg->sample_disk; P.soft_shadows = cfg->soft_shadows;
+  P.sample_mode = cfg->sample_mode; P.light_side = cfg->light_side; P.gamma = cfg->gamma; P.seed = cfg->seed;
+  P.stripe_h = tile->stripe_h > 0 ? tile->stripe_h : 0; P.stripe_stride = ss;
+  P.stats = s->d_stats;
+  P.stack_cap = (int32_t)cap;
+  P.lds_scene_f4 = lds_scene ? s->blob_f4 : 0;
+  const size_t lds_bytes = (size_t)P.lds_scene_f4 * sizeof(float4) + (size_t)cap * kBlock * sizeof(uint2) +
+                           (pt ? (size_t)2 * 3 * kBlock * sizeof(float4) : 0);
+
+  // rows per launch: whole 8-row tile bands, at most kMaxLaunchThreads threads
+  const uint32_t tiles_x = (uint32_t)(tile->w + 7) / 8;
+  uint32_t bands_per_launch = std::max<uint32_t>(1, kMaxLaunchThreads / (tiles_x * kBlock));
+  const uint32_t total_bands = (uint32_t)(tile->h + 7) / 8;
+  if (tile->stripe_h > 0 && sh % 8 == 0 && bands_per_launch >= (uint32_t)(sh / 8))
+    bands_per_launch = (bands_per_launch / (sh / 8)) * (sh / 8);  // chunks start on a stripe boundary
+  bands_per_launch = std::min(bands_per_launch, total_bands);
+  const uint32_t max_tiles = tiles_x * bands_per_launch;
+  const uint32_t max_per_xcd = (max_tiles + 7) / 8;
+  const uint32_t max_threads = max_per_xcd * 8 * kBlock;
+  const uint32_t levels = pt ? 0 : (uint32_t)cfg->max_depth;
+  if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * max_threads * sizeof(float4)))) return rc;
+  if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)spill_entries * max_threads * sizeof(uint2)))) return rc;
+  P.levels = (float4*)s->levels.p;
+  P.spill = (uint2*)s->spill.p;
+
+  if (stats) {
+    P3D_HIP(hipMemsetAsync(s->d_stats, 0, kNumStats * sizeof(unsigned long long), st));
+    P3D_HIP(hipEventRecord(s->ev0, st));
+  }
+  for (uint32_t band0 = 0; band0 < total_bands; band0 += bands_per_launch) {
+    const uint32_t nb = std::min(bands_per_launch, total_bands - band0);
+    const int row0 = (int)band0 * 8;
+    const int rows = std::min<int>((int)nb * 8, tile->h - row0);
+    // a chunk starts at local row row0; stripes make the image row a function of the LOCAL
+    // row of the whole tile, so pass the tile origin and offset the outputs instead
+    P.x0 = tile->x0; P.w = tile->w;
+    P.h = rows;
+    if (P.stripe_h > 0) {
+      if (row0 % sh != 0 && nb != total_bands) return fail(P3D_ERR_UNSUPPORTED, "stripe_h must divide 8-row bands when a tile is split into several launches");
+      P.y0 = tile->y0 + (row0 / sh) * sh * ss + (row0 % sh);
+    } else {
+      P.y0 = tile->y0 + row0;
+    }
+    P.tiles_x = tiles_x; P.tiles_y = nb;
+    const uint32_t ntiles = tiles_x * nb;
+    P.tiles_per_xcd = (ntiles + 7) / 8;
+    const uint32_t blocks = P.tiles_per_xcd * 8;
+    P.level_stride = blocks * kBlock;
+    const size_t off = (size_t)row0 * tile->w;
+    P.rgb = d_rgb ? d_rgb + 3 * off : nullptr;
+    P.hit_id = d_hit ? d_hit + off : nullptr;
+    P.rgb8 = d_rgb8 ? d_rgb8 + 3 * off : nullptr;
+    hipError_t e;
+    switch (cfg->accel) {
+      case P3D_ACCEL_BVH: e = launch_accel<P3D_ACCEL_BVH>(pt, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+      case P3D_ACCEL_GRID: e = launch_accel<P3D_ACCEL_GRID>(pt, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+      default: e = launch_accel<P3D_ACCEL_NONE>(pt, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+    }
+    if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+  }
+  if (stats) {
+    P3D_HIP(hipEventRecord(s->ev1, st));
+    P3D_HIP(hipEventSynchronize(s->ev1));
+    float ms = 0;
+    P3D_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    unsigned long long h[kNumStats];
+    P3D_HIP(hipMemcpy(h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    std::memset(stats, 0, sizeof(*stats));
+    stats->kernel_ms = ms;
+    stats->rays_primary = h[kRaysPrimary]; stats->rays_shadow = h[kRaysShadow]; stats->rays_reflect = h[kRaysReflect];
+    stats->rays_refract = h[kRaysRefract]; stats->rays_bounce = h[kRaysBounce]; stats->rays_light = h[kRaysLight];
+    stats->node_tests = h[kNodeTests]; stats->sphere_tests = h[kSphereTests]; stats->tri_tests = h[kTriTests];
+    stats->box_tests = h[kBoxTests]; stats->plane_tests = h[kPlaneTests]; stats->shaded_hits = h[kShadedHits];
+    stats->pixels = h[kPixels]; stats->max_stack = h[kMaxStack];
+  }
+  return P3D_OK;
+}
+
+int p3d_render_tile(p3d_scene* s, const p3d_config* cfg, const p3d_tile* tile, float* rgb, int32_t* hit_id, uint8_t* rgb8,
+                    p3d_stats* stats) {
+  if (!s || !cfg || !tile) return fail(P3D_ERR_INVALID, "p3d_render_tile: null argument");
+  if (tile->w <= 0 || tile->h <= 0) return fail(P3D_ERR_INVALID, "empty tile");
+  P3D_HIP(hipSetDevice(s->device));
+  const size_t n = (size_t)tile->w * tile->h;
+  if (rgb) if (int rc = s->out_rgb.ensure(n * 3 * sizeof(float))) return rc;
+  if (hit_id) if (int rc = s->out_hit.ensure(n * sizeof(int32_t))) return rc;
+  if (rgb8) if (int rc = s->out_rgb8.ensure(n * 3)) return rc;
+  p3d_stats local;
+  const int rc = p3d_render_tile_device(s, cfg, tile, rgb ? (float*)s->out_rgb.p : nullptr, hit_id ? (int32_t*)s->out_hit.p : nullptr,
+                                        rgb8 ? (uint8_t*)s->out_rgb8.p : nullptr, nullptr, stats ? stats : &local);
+  if (rc) return rc;
+  if (rgb) P3D_HIP(hipMemcpy(rgb, s->out_rgb.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (hit_id) P3D_HIP(hipMemcpy(hit_id, s->out_hit.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (rgb8) P3D_HIP(hipMemcpy(rgb8, s->out_rgb8.p, n * 3, hipMemcpyDeviceToHost));
+  return P3D_OK;
+}
+
+static int trace_common(p3d_scene* s, uint32_t accel, uint32_t n, const float* origin, const float* direction, int32_t* hit_id,
+                        float* hit_point, uint8_t* occluded, bool any) {
+  if (!s || !origin || !direction || (any ? !occluded : !hit_id)) return fail(P3D_ERR_INVALID, "p3d_trace: null argument");
+  if (int rc = check_accel(s, accel)) return rc;
+  if (accel == P3D_ACCEL_GRID && s->dev.n_objs == 0) return fail(P3D_ERR_UNSUPPORTED, "grid over an empty scene");
+  if (n == 0) return P3D_OK;
+  P3D_HIP(hipSetDevice(s->device));
+  const size_t in_bytes = (size_t)n * 6 * sizeof(float);
+  const size_t out_bytes = (size_t)n * (sizeof(int32_t) + 3 * sizeof(float) + 1) + 64;
+  if (int rc = s->q_in.ensure(in_bytes)) return rc;
+  if (int rc = s->q_out.ensure(out_bytes)) return rc;
+  float* d_o = (float*)s->q_in.p;
+  float* d_d = d_o + (size_t)n * 3;
+  int32_t* d_hit = (int32_t*)s->q_out.p;
+  float* d_hp = (float*)(d_hit + n);
+  uint8_t* d_occ = (uint8_t*)(d_hp + (size_t)n * 3);
+  P3D_HIP(hipMemcpy(d_o, origin, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  P3D_HIP(hipMemcpy(d_d, direction, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
+  const uint32_t bound = accel == P3D_ACCEL_BVH ? std::max<uint32_t>(1, s->bvh_max_depth) : 1;
+  const uint32_t cap = std::min<uint32_t>(bound, 24);
+  const uint32_t blocks = (n + kBlock - 1) / kBlock;
+  if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)(bound - cap) * blocks * kBlock * sizeof(uint2)))) return rc;
+  TraceParams P{};
+  P.sc = s->dev; P.n = n; P.origin = d_o; P.direction = d_d; P.hit_id = d_hit; P.hit_point = d_hp; P.occluded = d_occ;
+  P.t = nullptr; P.spill = (uint2*)s->spill.p; P.spill_stride = blocks * kBlock; P.stack_cap = (int32_t)cap;
+  const size_t lds = (size_t)cap * kBlock * sizeof(uint2);
+#define P3D_TRACE(A)                                                                                     \
+  do {                                                                                                   \
+    if (any) hipLaunchKernelGGL((trace_kernel<A, true>), dim3(blocks), dim3(kBlock), lds, 0, P);         \
+    else hipLaunchKernelGGL((trace_kernel<A, false>), dim3(blocks), dim3(kBlock), lds, 0, P);            \
+  } while (0)
+  if (accel == P3D_ACCEL_BVH) P3D_TRACE(P3D_ACCEL_BVH);
+  else if (accel == P3D_ACCEL_GRID) P3D_TRACE(P3D_ACCEL_GRID);
+  else P3D_TRACE(P3D_ACCEL_NONE);
+#undef P3D_TRACE
+  P3D_HIP(hipGetLastError());
+  P3D_HIP(hipDeviceSynchronize());
+  if (any) {
+    P3D_HIP(hipMemcpy(occluded, d_occ, n, hipMemcpyDeviceToHost));
+  } else {
+    P3D_HIP(hipMemcpy(hit_id, d_hit, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (hit_point) P3D_HIP(hipMemcpy(hit_point, d_hp, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  return P3D_OK;
+}
+
+int p3d_trace_closest(p3d_scene* s, uint32_t accel, uint32_t n, const float* origin, const float* direction, int32_t* hit_id,
+                      float* t, float* hit_point) {
+  (void)t;  // BVH / grid report the hit point only (bvh.cpp:271, grid.cpp:110); kept for ABI symmetry
+  return trace_common(s, accel, n, origin, direction, hit_id, hit_point, nullptr, false);
+}
+int p3d_trace_any(p3d_scene* s, uint32_t accel, uint32_t n, const float* origin, const float* direction, uint8_t* occluded) {
+  return trace_common(s, accel, n, origin, direction, nullptr, nullptr, occluded, true);
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// pt_kernel.hpp — the path tracer (Radiance, main.cpp:313-516) as a persistent per-lane
+// bounce loop.
+//
+// The reference recurses:  R = E + e + f * R(child).  Here every lane owns one pixel and
+// runs ONE flat loop whose body is a single bounce; a lane whose path ended starts its next
+// sample (or pops its pending dielectric branch) in the same iteration instead of waiting
+// for the slowest lane of the wave, so the wave only idles lanes in the very last
+// iterations of a tile ("persistent threads", north_star).  Radiance is carried as
+//     L += T * (E + e);   T *= f
+// which is the same sum evaluated outermost-first (the recursion evaluates innermost-
+// first): results agree with the recursive oracle to float rounding (~1e-6 relative),
+// far inside the 1e-4 tolerance; hit decisions and the RNG stream are identical.
+//
+// sin/cos: the reference calls libm (cosf/sinf main.cpp:400, cos/sin main.cpp:436).  libm
+// differs between platforms by an ulp, which flips rare hit decisions and would make CPU
+// and GPU paths diverge visibly at 256 spp.  Both this kernel and the oracle therefore use
+// the same explicit double-precision routine (det_sincos) built from + - * floor only.
+#pragma once
+
+#include "kernels.hpp"
+
+namespace p3d {
+
+__device__ __forceinline__ void det_sincos(double x, double& s_out, double& c_out) {
+  const double two_over_pi = 6.36619772367581382433e-01;
+  const double pio2_hi = 1.57079632673412561417e+00, pio2_lo = 6.07710050650619224932e-11;
+  const double kd = floor(x * two_over_pi + 0.5);
+  const double r = (x - kd * pio2_hi) - kd * pio2_lo;
+  const double z = r * r;
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double sp = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double s = r + (z * r) * (S1 + z * sp);
+  const double cp = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double c = 1.0 - (0.5 * z - z * cp);
+  const long long k = (long long)kd;
+  switch (k & 3) {
+    case 0: s_out = s; c_out = c; break;
+    case 1: s_out = c; c_out = -s; break;
+    case 2: s_out = -s; c_out = -c; break;
+    default: s_out = -c; c_out = s; break;
+  }
+}
+
+constexpr float kPIf = 3.141592653589793238462f;  // camera.h:13
+
+// pending dielectric branch (main.cpp:512-513): 3 float4 per entry, 2 entries per lane
+struct Pending {
+  float4* base;  // &pend[lane]; float4 q of entry e at base[(e * 3 + q) * kBlock]
+  int n;
+};
+
+template <int ACCEL, bool LDS, bool STATS>
+__global__ void __launch_bounds__(kBlock) pt_kernel(const RenderParams P) {
+  extern __shared__ float4 smem[];
+  uint32_t tx, ty;
+  if (!tile_of_block(P, tx, ty)) return;
+  DevScene sc = P.sc;
+  stage_scene<LDS>(sc, P, smem);
+
+  const uint32_t lane = threadIdx.x;
+  const int c = (int)(tx * 8 + (lane & 7)), r = (int)(ty * 8 + (lane >> 3));
+  Counters<STATS> ct;
+  if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
+  Stack st;
+  st.base = reinterpret_cast<uint2*>(smem + P.lds_scene_f4) + lane;
+  st.spill = P.spill + (blockIdx.x * kBlock + lane);
+  st.spill_stride = P.level_stride;
+  st.sp = 0;
+  st.cap = P.stack_cap;
+  Pending pend;
+  pend.base = smem + P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2 + lane;  // after the node stack
+  pend.n = 0;
+
+  const bool active = c < P.w && r < P.h;
+  if (active) {
+    const int sh = P.stripe_h > 0 ? P.stripe_h : 1, ss = P.stripe_h > 0 ? P.stripe_stride : 1;
+    const int x = P.x0 + c;
+    const int y = P.y0 + (r / sh) * sh * ss + (r % sh);
+    const int SPP = (int)P.spp_sqrt;
+    const int n_samples = SPP * SPP;
+    const int MAXD = P.max_depth;
+    ct.add(kPixels);
+
+    F3 color = f3(0, 0, 0);  // pixel accumulator (main.cpp:792)
+    int first_hit = -1;
+    int s = 0;               // next sample to start
+    bool alive = false, in_sample = false, first_ray = false;
+    Rng rng;
+    RayS ray;
+    F3 T = f3(1, 1, 1), L = f3(0, 0, 0);
+    int depth = 0;
+
+    while (true) {
+      if (!alive) {
+        if (pend.n > 0) {  // resume the deferred reflection branch of a dielectric hit
+          --pend.n;
+          const float4 q0 = pend.base[(pend.n * 3 + 0) * kBlock], q1 = pend.base[(pend.n * 3 + 1) * kBlock],
+                       q2 = pend.base[(pend.n * 3 + 2) * kBlock];
+          ray_set(ray, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y));
+          T = f3(q1.z, q1.w, q2.x);
+          depth = __float_as_int(q2.y);
+          alive = true;
+        } else {
+          if (in_sample) {
+            color = color + L;
+            in_sample = false;
+          }
+          if (s == n_samples) break;
+          const int si = s / SPP, sj = s % SPP;
+          rng.seed_stream(P.seed, (uint32_t)(y * sc.cam.res_x + x), (uint32_t)s);
+          st.sp = 0;
+          F3 o, d;
+          make_primary(P, sc.cam, x, y, si, sj, rng, o, d);
+          ray_set(ray, o, d);
+          ct.add(kRaysPrimary);
+          T = f3(1, 1, 1);
+          L = f3(0, 0, 0);
+          depth = MAXD;
+          first_ray = (s == 0);
+          ++s;
+          alive = true;
+          in_sample = true;
+        }
+      }
+      // ---- one bounce: the body of Radiance ----
+      F3 Pn;
+      Geom g;
+      const int obj = closest_hit<ACCEL>(sc, st, ray, Pn, g, ct);
+      if (first_ray) { first_hit = obj; first_ray = false; }
+      if (obj < 0 || depth == 0) {  // main.cpp:350-355: the background acts as an environment light
+        L = L + T * sc.bg;
+        alive = false;
+        continue;
+      }
+      ct.add(kShadedHits);
+      const uint32_t m = geom_material(g);
+      const float4 m0 = sc.mats[4 * m], m1 = sc.mats[4 * m + 1], m2 = sc.mats[4 * m + 2], m3 = sc.mats[4 * m + 3];
+      const F3 E = xyz(m3);
+      const F3 norm = get_normal(g, sc.normals, Pn);                         // main.cpp:366
+      const F3 norml = (dot(norm, ray.d) < 0) ? norm : norm * -1.0f;         // main.cpp:368
+      const F3 intercept_out = offset_intersection(Pn, norm);
+      const F3 intercept_in = offset_intersection(Pn, norm * -1.0f);
+      F3 f = xyz(m0);
+      const float p = max3_ref(f.x, f.y, f.z);
+      if (--depth <= MAXD - 5) {  // Russian roulette, main.cpp:382-388
+        if (rng.rand_float() < p) {
+          f = f * (1 / p);
+        } else {
+          L = L + T * E;
+          alive = false;
+          continue;
+        }
+      }
+      if (m0.w == 1.0f) {  // ideal diffuse, main.cpp:391-480
+        const float r1 = 2 * kPIf * rng.rand_float();
+        const float r2 = rng.rand_float();
+        const float r2s = sqrtf(r2);
+        const F3 w = norml;
+        const F3 u = normalized(cross(gt_0p1(fabsf(w.x)) ? f3(0, 1, 0) : f3(1, 0, 0), w));
+        const F3 v = cross(w, u);
+        double s1, c1;
+        det_sincos((double)r1, s1, c1);
+        const F3 d = normalized((u * (float)c1 * r2s + v * (float)s1 * r2s) + w * sqrtf(1 - r2));
+        F3 e = f3(0, 0, 0);
+        for (uint32_t k = 0; k < sc.n_emitters; ++k) {  // explicit light sampling, main.cpp:407-477
+          const uint32_t lobj = sc.emitters[k];
+          const Geom lg = load_geom(sc.ogeom, lobj);
+          const F3 emi = xyz(sc.mats[4 * geom_material(lg) + 3]);
+          const F3 center = f3(lg.a.x, lg.a.y, lg.a.z);
+          const float rad = lg.a.w;
+          const F3 sw = center - intercept_out;
+          const F3 su = normalized(cross(gt_0p1(fabsf(sw.x)) ? f3(0, 1, 0) : f3(1, 0, 0), sw));
+          const F3 sv = cross(sw, su);
+          const F3 ic = intercept_out - center;
+          const double cos_a_max = sqrt(1 - ((double)rad * (double)rad) / (double)dot(ic, ic));
+          const double eps1 = rng.erand48();
+          const double eps2 = rng.erand48();
+          const double cos_a = 1 - eps1 + eps1 * cos_a_max;
+          const double sin_a = sqrt(1 - cos_a * cos_a);
+          const double phi = (double)(2 * kPIf) * eps2;
+          double sphi, cphi;
+          det_sincos(phi, sphi, cphi);
+          const F3 l = normalized((su * (float)cphi * (float)sin_a + sv * (float)sphi * (float)sin_a) + sw * (float)cos_a);
+          RayS feeler;
+          ray_set(feeler, intercept_out, l);
+          ct.add(kRaysLight);
+          F3 hp2;
+          Geom g2;
+          const int hit2 = closest_hit<ACCEL>(sc, st, feeler, hp2, g2, ct);
+          if (hit2 >= 0 && hit2 == (int)lobj) {  // main.cpp:472-475
+            const double omega = (double)(2 * kPIf) * (1 - cos_a_max);
+            e = e + f * (emi * dot(l, norml) * (float)omega) * (1 / kPIf);
+          }
+        }
+        L = L + T * (E + e);
+        T = T * f;
+        ray_set(ray, intercept_out, d);
+        ct.add(kRaysBounce);
+        continue;
+      }
+      if (m1.w == 1.0f) {  // mirror, main.cpp:481-484
+        L = L + T * E;
+        T = T * f;
+        ray_set(ray, intercept_out, ray.d - norm * (2 * dot(norm, ray.d)));
+        ct.add(kRaysBounce);
+        continue;
+      }
+      // dielectric, main.cpp:486-515
+      const F3 refl_d = ray.d - norm * 2 * dot(norm, ray.d);
+      const bool into = dot(norm, norml) > 0;
+      const double nc = 1.0, nt = (double)m2.z;
+      const double nnt = into ? nc / nt : nt / nc;
+      const double ddn = (double)dot(ray.d, norml);
+      const double cos2t = 1 - nnt * nnt * (1 - ddn * ddn);
+      L = L + T * E;
+      T = T * f;
+      if (cos2t < 0) {  // total internal reflection
+        ray_set(ray, intercept_out, refl_d);
+        ct.add(kRaysBounce);
+        continue;
+      }
+      const F3 tdir = normalized(ray.d * (float)nnt - norm * (float)((into ? 1 : -1) * (ddn * nnt + sqrt(cos2t))));
+      const double a = nt - nc, b = nt + nc;
+      const double R0 = (a * a) / (b * b);
+      const double cc = 1 - (into ? -ddn : (double)dot(tdir, norm));
+      const double Re = R0 + (1 - R0) * cc * cc * cc * cc * cc;
+      const double Tr = 1 - Re;
+      const double Pp = 0.25 + 0.5 * Re;
+      const double RP = Re / Pp, TP = Tr / (1 - Pp);
+      if (depth <= MAXD - 2) {  // main.cpp:509-511: choose one
+        if (rng.erand48() < Pp) {
+          T = T * (float)RP;
+          ray_set(ray, intercept_out, refl_d);
+        } else {
+          T = T * (float)TP;
+          ray_set(ray, intercept_out, tdir);
+        }
+        ct.add(kRaysBounce);
+      } else {  // first two bounces trace both; g++ evaluates the transmission operand first
+        {  // at most two levels fork (depth > MAX_DEPTH-2), so two pending entries suffice
+          const F3 Tr_ = T * (float)Re;
+          pend.base[(pend.n * 3 + 0) * kBlock] = make_float4(intercept_out.x, intercept_out.y, intercept_out.z, refl_d.x);
+          pend.base[(pend.n * 3 + 1) * kBlock] = make_float4(refl_d.y, refl_d.z, Tr_.x, Tr_.y);
+          pend.base[(pend.n * 3 + 2) * kBlock] = make_float4(Tr_.z, __int_as_float(depth), 0, 0);
+          ++pend.n;
+        }
+        T = T * (float)Tr;
+        ray_set(ray, intercept_in, tdir);
+        ct.add(kRaysBounce, 2);
+      }
+    }
+    if (P.antialiasing) color = color / (float)(SPP * SPP);  // main.cpp:800
+
+    const size_t k = (size_t)r * P.w + c;
+    if (P.rgb) {
+      P.rgb[3 * k] = color.x; P.rgb[3 * k + 1] = color.y; P.rgb[3 * k + 2] = color.z;
+    }
+    if (P.hit_id) P.hit_id[k] = first_hit;
+    if (P.rgb8) {
+      F3 gc = color;
+      if (P.gamma != 1.0f) {
+        const double ig = (double)(1 / P.gamma);
+        gc = f3((float)pow((double)color.x, ig), (float)pow((double)color.y, ig), (float)pow((double)color.z, ig));
+      }
+      P.rgb8[3 * k] = u8fromfloat(gc.x); P.rgb8[3 * k + 1] = u8fromfloat(gc.y); P.rgb8[3 * k + 2] = u8fromfloat(gc.z);
+    }
+  }
+  if (STATS) flush_stats<STATS>(ct, P.stats);
+}
+
+}  // namespace p3d

@@ -1,0 +1,119 @@
+// p3d_render — the console front end.  Does what the reference's main() does when its GL
+// window is off (main.cpp:1004-1019): ask for a scene, load it, render a frame, print the
+// time, save the image — with the frame loop (main.cpp:747-820) running on the MI355X
+// through include/p3d.h.  Options that are #defines in constants.h are flags here.
+//
+//   p3d_render [scene.p3f] [--whitted|--pathtrace] [--accel none|grid|bvh] [--depth N]
+//              [--spp N(sqrt)] [--aa 0|1] [--dof 0|1] [--soft 0|1] [--tent] [--gamma G]
+//              [--res W H] [--seed S] [--legacy-f11] [--out image.ppm] [--device D]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "p3d.h"
+
+namespace {
+
+int die(const char* what) {
+  std::fprintf(stderr, "%s: %s\n", what, p3d_last_error());
+  return 1;
+}
+
+// img_Data is stored bottom row first (main.cpp:818-820, y = 0 at the bottom); image files
+// start with the top row, so rows are written in reverse.
+bool save_ppm(const std::string& path, const std::vector<uint8_t>& rgb8, int w, int h) {
+  std::ofstream f(path, std::ios::binary);
+  if (!f) return false;
+  f << "P6\n" << w << " " << h << "\n255\n";
+  for (int y = h - 1; y >= 0; --y) f.write(reinterpret_cast<const char*>(&rgb8[(size_t)y * w * 3]), (std::streamsize)w * 3);
+  return (bool)f;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  p3d_config cfg;
+  p3d_config_default(&cfg);
+  std::string scene_path, out = "RT_Output.ppm";  // main.cpp:851 writes RT_Output.png
+  int res_w = 0, res_h = 0, device = 0;
+  uint32_t load_flags = 0;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto next = [&](const char* name) -> const char* {
+      if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", name); std::exit(2); }
+      return argv[++i];
+    };
+    if (a == "--whitted") cfg.integrator = P3D_WHITTED;
+    else if (a == "--pathtrace") cfg.integrator = P3D_PATHTRACE;
+    else if (a == "--accel") {
+      const std::string v = next("--accel");
+      cfg.accel = v == "none" ? P3D_ACCEL_NONE : (v == "grid" ? P3D_ACCEL_GRID : P3D_ACCEL_BVH);
+    } else if (a == "--depth") cfg.max_depth = std::atoi(next("--depth"));
+    else if (a == "--spp") cfg.spp_sqrt = (uint32_t)std::atoi(next("--spp"));
+    else if (a == "--aa") cfg.antialiasing = (uint32_t)std::atoi(next("--aa"));
+    else if (a == "--dof") cfg.depth_of_field = (uint32_t)std::atoi(next("--dof"));
+    else if (a == "--soft") cfg.soft_shadows = (uint32_t)std::atoi(next("--soft"));
+    else if (a == "--tent") cfg.sample_mode = P3D_SAMPLE_TENT;
+    else if (a == "--gamma") cfg.gamma = (float)std::atof(next("--gamma"));
+    else if (a == "--seed") cfg.seed = std::strtoull(next("--seed"), nullptr, 0);
+    else if (a == "--res") { res_w = std::atoi(next("--res")); res_h = std::atoi(next("--res")); }
+    else if (a == "--legacy-f11") load_flags |= P3D_LOAD_LEGACY_F11;
+    else if (a == "--out") out = next("--out");
+    else if (a == "--device") device = std::atoi(next("--device"));
+    else if (a[0] != '-') scene_path = a;
+    else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+  }
+  if (scene_path.empty()) {  // main.cpp:968-980: prompt for a name under P3D_Scenes/
+    std::string name;
+    std::cout << "Input the Scene Name: ";
+    if (!(std::cin >> name)) return 2;
+    scene_path = "P3D_Scenes/" + name;
+  }
+
+  p3d_host_scene* hs = nullptr;
+  if (p3d_host_scene_load(scene_path.c_str(), load_flags, &hs) != P3D_OK) {
+    std::printf("\nError opening P3F file.\n");
+    return die("load");
+  }
+  if (res_w > 0 && p3d_host_scene_set_resolution(hs, res_w, res_h) != P3D_OK) return die("resolution");
+  if (cfg.soft_shadows && !cfg.antialiasing &&  // main.cpp:725-745
+      p3d_host_scene_replicate_lights(hs, cfg.spp_sqrt, cfg.light_side) != P3D_OK)
+    return die("lights");
+
+  const auto t_build0 = std::chrono::high_resolution_clock::now();
+  const p3d_scene_desc* desc = nullptr;
+  if (p3d_host_scene_desc(hs, cfg.accel == P3D_ACCEL_BVH, cfg.accel == P3D_ACCEL_GRID, &desc) != P3D_OK) return die("flatten");
+  const int W = desc->camera.res_x, H = desc->camera.res_y;
+  std::printf("\nResolutionX = %d  ResolutionY= %d.\n", W, H);  // main.cpp:986
+  p3d_scene* scene = nullptr;
+  if (p3d_scene_create(desc, device, &scene) != P3D_OK) return die("scene_create");
+  const auto t_build1 = std::chrono::high_resolution_clock::now();
+
+  std::vector<uint8_t> img((size_t)3 * W * H);
+  p3d_tile tile{0, 0, W, H, 0, 1};
+  p3d_stats st{};
+  cfg.collect_stats = 1;
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  if (p3d_render_tile(scene, &cfg, &tile, nullptr, nullptr, img.data(), &st) != P3D_OK) return die("render");
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  std::printf("Drawing finished!\n");
+  const double secs = std::chrono::duration<double>(t1 - t0).count();
+  const uint64_t rays = st.rays_primary + st.rays_shadow + st.rays_reflect + st.rays_refract + st.rays_bounce + st.rays_light;
+  std::printf("\nDone: %.2f (sec)\n", secs);  // main.cpp:1012
+  std::printf("accel build + upload %.3f s; kernel %.3f ms; %llu rays; %.1f Mrays/s (kernel)\n",
+              std::chrono::duration<double>(t_build1 - t_build0).count(), st.kernel_ms, (unsigned long long)rays,
+              st.kernel_ms > 0 ? rays / (st.kernel_ms * 1e3) : 0.0);
+  if (!save_ppm(out, img, W, H)) {
+    std::printf("Error saving Image file\n");
+    return 1;
+  }
+  std::printf("Image file created\n");
+  p3d_scene_destroy(scene);
+  p3d_host_scene_destroy(hs);
+  return 0;
+}
