@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the ray-trace hot path on MI355X (BASELINE.json metric).
+
+A step = one frame of the workload rendered by the HIP path into HBM-resident buffers
+(+ for N > 1 the RCCL gather of the per-rank stripe buffers to rank 0 and the
+de-interleave into the frame).  Workload at N = 1: BASELINE.json configs[1] =
+balls_low.p3f at 1024x1024, Whitted, MAX_DEPTH 4, BVH.  For N > 1 the frame grows so
+that every GPU keeps 1024*1024 pixels of the same picture (weak scaling; N = 4 is the
+2048x2048 of configs[3]); rows are dealt to ranks in 8-row stripes, round-robin.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|tri100k|cornell_pt]
+
+Prints ONE JSON line on rank 0.  `roofline` and `cpu_baseline` follow DESIGN.md §Measurement.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "tri100k", "cornell_pt"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def workload_setup(name, n_gpus, p3d):
+    """-> (scene path, config, base resolution, description)"""
+    scenes = os.path.join(ROOT, "tests", "golden", "scenes")
+    if name == "cfg2":
+        return (os.path.join(scenes, "balls_low.p3f"), p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4), 1024,
+                "balls_low.p3f, Whitted MAX_DEPTH=4, BVH, no AA (BASELINE configs[1])")
+    if name == "tri100k":
+        sys.path.insert(0, os.path.join(ROOT, "scenes"))
+        import make_tri100k
+        path = "/tmp/p3d_tri100k_%d.p3f" % os.getuid()
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0 and not os.path.exists(path):
+            make_tri100k.generate(path + ".tmp", res=1024)
+            os.replace(path + ".tmp", path)
+        while not os.path.exists(path):
+            time.sleep(0.2)
+        return (path, p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=6), 1024,
+                "100k random triangles, Whitted MAX_DEPTH=6, BVH (BASELINE configs[3] scene)")
+    return (os.path.join(ROOT, "scenes", "cornell.p3f"), p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=4, max_depth=20),
+            512, "cornell.p3f, path tracer 16 spp, BVH (BASELINE configs[2] scene, reduced spp)")
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import p3d_amd as p3d
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    scene_path, cfg, base, desc = workload_setup(args.workload, world, p3d)
+    stripe_h = 8
+    res = int(round(base * math.sqrt(world) / (stripe_h * world))) * stripe_h * world  # multiple of stripe_h*N
+    hs = p3d.HostScene(scene_path)
+    hs.set_resolution(res, res)
+    dev = p3d.DeviceScene(hs, bvh=True, device=local_rank)
+    tile = p3d.stripe_tile((res, res), rank, world, stripe_h) if world > 1 else dev.full_tile()
+    n_local = tile.w * tile.h
+    stream = torch.cuda.current_stream()
+
+    # per-rank buffers [rgb float32 x3 | hit int32] in one allocation so that one collective moves both
+    def new_buf():
+        return torch.empty(n_local * 16, dtype=torch.uint8, device="cuda")
+    bufs = [new_buf(), new_buf()]
+    handles = [None, None]
+    gathered = [[torch.empty_like(bufs[0]) for _ in range(world)] for _ in range(2)] if (world > 1 and rank == 0) else None
+    frame_rgb = torch.empty((res, res, 3), dtype=torch.float32, device="cuda") if rank == 0 and world > 1 else None
+    frame_hit = torch.empty((res, res), dtype=torch.int32, device="cuda") if rank == 0 and world > 1 else None
+
+    def assemble(slot):
+        # rows of stripe s of rank r sit at frame rows (s*world + r)*stripe_h ..: stack on a new axis
+        n_str = res // (stripe_h * world)
+        parts = [g[: n_local * 12].view(torch.float32).view(n_str, stripe_h, res, 3) for g in gathered[slot]]
+        frame_rgb.view(n_str, world, stripe_h, res, 3).copy_(torch.stack(parts, dim=1))
+        hits = [g[n_local * 12:].view(torch.int32).view(n_str, stripe_h, res) for g in gathered[slot]]
+        frame_hit.view(n_str, world, stripe_h, res).copy_(torch.stack(hits, dim=1))
+
+    ev_pairs = []
+
+    def step(i, timed):
+        slot = i & 1
+        if handles[slot] is not None:
+            handles[slot].wait()
+            if rank == 0:
+                assemble(slot)
+            handles[slot] = None
+        b = bufs[slot]
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        dev.render_device(cfg, tile, d_rgb=b.data_ptr(), d_hit=b.data_ptr() + n_local * 12, stream=stream.cuda_stream)
+        if timed:
+            e1.record(stream)
+            ev_pairs.append((e0, e1))
+        if world > 1:
+            handles[slot] = dist.gather(b, gathered[slot] if rank == 0 else None, dst=0, async_op=True)
+
+    def drain():
+        for slot in (0, 1):
+            if handles[slot] is not None:
+                handles[slot].wait()
+                if rank == 0:
+                    assemble(slot)
+                handles[slot] = None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    drain()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    drain()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+
+    # counts (deterministic): one counted pass of this rank's tile outside the timed region
+    cfg_counted = p3d.Config.from_buffer_copy(bytes(cfg))
+    cfg_counted.collect_stats = 1
+    st = p3d.Stats()
+    dev.render_device(cfg_counted, tile, d_rgb=bufs[0].data_ptr(), d_hit=bufs[0].data_ptr() + n_local * 12,
+                      stream=stream.cuda_stream, stats=st)
+    counts = torch.tensor([st.rays, st.algorithmic_bytes()], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts)
+    rays_total, _ = counts.tolist()
+
+    if rank == 0:
+        value = rays_total * args.steps / dt / 1e6
+        alg_bytes_launch = st.algorithmic_bytes()  # rank 0's launch
+        achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm_bytes.json")
+        if os.path.exists(prof) and args.workload == "cfg2" and world == 1:
+            traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "Mrays/s (primary+secondary)", "value": round(value, 1), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "resolution": [res, res], "rays_per_frame": int(rays_total),
+                       "ray_definition": "one traversal query (closest-hit or any-hit)",
+                       "parallelism": "image rows in %d-row stripes, round-robin over %d GPU(s)%s"
+                                      % (stripe_h, world, "; RCCL gather to rank 0" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                         "kernel": "whitted_kernel" if cfg.integrator == p3d.WHITTED or not cfg.antialiasing else "pt_kernel",
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_launch),
+                         "note": "algorithmic bytes (DESIGN.md) are served from LDS/L2, not HBM: the kernel is "
+                                 "VALU/latency bound; traffic = measured HBM bytes"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload, scene_path, cfg, res)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(workload, scene_path, cfg, res):
+    """The oracle (CPU port of the reference's algorithm, literal semantics) on this host:
+    1 thread, as the reference is single-threaded.  Bounded sample: whole frames of the same
+    workload for cfg2 (about 1 s each), a centred crop for the heavier ones."""
+    from oracle import binding as ob
+    sc = ob.Scene(scene_path)
+    sc.set_resolution(res, res)
+    ocfg = ob.default_config(integrator=cfg.integrator, accel=cfg.accel, max_depth=cfg.max_depth,
+                             spp_sqrt=cfg.spp_sqrt, antialiasing=cfg.antialiasing,
+                             depth_of_field=cfg.depth_of_field, sample_disk=cfg.sample_disk,
+                             soft_shadows=cfg.soft_shadows, sample_mode=cfg.sample_mode, seed=cfg.seed,
+                             rng_mode=0, stack_mode=1, trace_zero_weight=1, math_mode=0, threads=1)
+    if workload == "cfg2":
+        x0 = y0 = 0
+        w = h = res
+        reps = 5
+        sample = "%d whole frames of the same workload (%dx%d), best of %d" % (reps, res, res, reps)
+    else:
+        w = h = 256
+        x0 = y0 = (res - 256) // 2
+        reps = 2
+        sample = "centred %dx%d crop of the %dx%d frame, best of %d" % (w, h, res, res, reps)
+    sc.render(ocfg, x0, y0, 8, 8)  # builds the BVH outside the timed region
+    best, rays = None, 0
+    for _ in range(reps):
+        _, _, st = sc.render(ocfg, x0, y0, w, h)
+        if best is None or st.seconds < best:
+            best, rays = st.seconds, st.rays
+    out = {"value": round(rays / best / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample}
+    # all host cores (rows dealt round-robin), parallel semantics; informational
+    n = os.cpu_count() or 1
+    ocfg.stack_mode = 0
+    ocfg.trace_zero_weight = 0
+    ocfg.threads = n
+    _, _, st = sc.render(ocfg, x0, y0, w, h)
+    out["all_cores"] = {"value": round(st.rays / st.seconds / 1e6, 3), "cores": n}
+    return out
+
+
+if __name__ == "__main__":
+    main()

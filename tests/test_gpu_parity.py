@@ -61,3 +61,196 @@ def test_whitted_balls_low_256(accel, depth):
     # and against the reference-literal semantics
     l_rgb, l_hit, _ = sc.render(oracle_cfg_like(cfg, stack_mode=1, trace_zero_weight=1, threads=1))
     compare((rgb, hit), (l_rgb, l_hit), TOL)
+
+
+def _pair(scene_file, res=None, legacy=False, bvh=True, grid=True, lens=None):
+    hs = p3d.HostScene(scene_file, legacy_f11=legacy)
+    sc = ob.Scene(scene_file, legacy_f11=legacy)
+    if res:
+        hs.set_resolution(*res)
+        sc.set_resolution(*res)
+    if lens:
+        hs.set_lens(*lens)
+        sc.set_lens(*lens)
+    return p3d.DeviceScene(hs, bvh=bvh, grid=grid), sc
+
+
+@pytest.mark.parametrize("accel", [p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH])
+def test_whitted_triangle_soup(tri5k_path, accel):
+    """5000 random triangles, depth 6: scene too big for LDS staging -> global-memory path,
+    deep BVH, node stack spill area in use."""
+    dev, sc = _pair(tri5k_path, res=(192, 192))
+    cfg = p3d.whitted_config(accel=accel, max_depth=6, collect_stats=1)
+    rgb, hit, st = dev.render(cfg)
+    o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+    compare((rgb, hit), (o_rgb, o_hit), 2e-6)
+    assert st.rays == o_st.rays and st.node_tests == o_st.node_tests and st.tri_tests == o_st.tri_tests
+    assert st.max_stack == o_st.max_stack
+    l_rgb, l_hit, _ = sc.render(oracle_cfg_like(cfg, stack_mode=1, trace_zero_weight=1, threads=1))
+    compare((rgb, hit), (l_rgb, l_hit), TOL)
+
+
+@pytest.mark.parametrize("scene,legacy", [("balls_box.p3f", True), ("box.p3f", True), ("mount_low.p3f", True),
+                                          ("tri_low.p3f", True), ("balls_medium.p3f", True),
+                                          ("path_glass.p3f", False), ("balls_dof.p3f", False)])
+@pytest.mark.parametrize("accel", [p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH])
+def test_whitted_other_scenes(scene, legacy, accel):
+    """aaBox objects, transmissive materials (refraction chain, `inside` rays), legacy `f` lines."""
+    dev, sc = _pair(scene_path(scene), res=(160, 160), legacy=legacy)
+    cfg = p3d.whitted_config(accel=accel, max_depth=5, collect_stats=1)
+    rgb, hit, st = dev.render(cfg)
+    o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+    compare((rgb, hit), (o_rgb, o_hit), 2e-6)
+    assert st.rays == o_st.rays
+    assert (st.rays_refract, st.rays_reflect, st.box_tests) == (o_st.rays_refract, o_st.rays_reflect, o_st.box_tests)
+
+
+def test_empty_scene_renders_background():
+    """balls_medium through the shipped parser = 0 objects: every pixel is bclr."""
+    dev, sc = _pair(scene_path("balls_medium.p3f"), res=(64, 64), grid=False)
+    for accel in (p3d.ACCEL_NONE, p3d.ACCEL_BVH):
+        rgb, hit, st = dev.render(p3d.whitted_config(accel=accel, max_depth=3, collect_stats=1))
+        assert (hit == -1).all()
+        assert (rgb == sc.background()[None, None, :]).all()
+        assert st.rays == 64 * 64
+
+
+@pytest.mark.parametrize("kw", [dict(antialiasing=1, spp_sqrt=3), dict(antialiasing=1, spp_sqrt=2, soft_shadows=1),
+                                dict(antialiasing=1, spp_sqrt=2, sample_mode=1),
+                                dict(antialiasing=1, spp_sqrt=2, depth_of_field=1, sample_disk=1),
+                                dict(antialiasing=1, spp_sqrt=2, depth_of_field=1, sample_disk=0)])
+def test_whitted_sampling_modes(kw):
+    """AA jitter / tent, soft shadows with per-sample light jitter, thin-lens DOF (main.cpp:758-802,180-186)."""
+    dev, sc = _pair(scene_path("balls_dof.p3f" if kw.get("depth_of_field") else "balls_low.p3f"), res=(96, 96))
+    cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=3, seed=77, **kw)
+    rgb, hit, _ = dev.render(cfg)
+    o_rgb, o_hit, _ = sc.render(oracle_cfg_like(cfg))
+    compare((rgb, hit), (o_rgb, o_hit), 2e-6)
+
+
+def test_soft_shadows_by_light_replication():
+    """!ANTIALIASING && SOFT_SHADOWS: every light becomes SPP x SPP lights (main.cpp:725-745)."""
+    hs = p3d.HostScene(scene_path("balls_low.p3f"))
+    hs.set_resolution(96, 96)
+    hs.replicate_lights(3, 0.5)
+    sc = ob.Scene(scene_path("balls_low.p3f"))
+    sc.set_resolution(96, 96)
+    sc.replicate_lights(3, 0.5)
+    assert sc.counts()["lights"] == 27
+    dev = p3d.DeviceScene(hs, bvh=True, grid=False)
+    cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=2, soft_shadows=1)
+    rgb, hit, _ = dev.render(cfg)
+    o_rgb, o_hit, _ = sc.render(oracle_cfg_like(cfg))
+    compare((rgb, hit), (o_rgb, o_hit), 5e-6)
+
+
+@pytest.mark.parametrize("scene,accel,dof", [("path_balls.p3f", p3d.ACCEL_BVH, 0), ("path_balls.p3f", p3d.ACCEL_NONE, 0),
+                                             ("path_mirror.p3f", p3d.ACCEL_BVH, 0), ("path_glass.p3f", p3d.ACCEL_BVH, 0),
+                                             ("path_glass.p3f", p3d.ACCEL_GRID, 0), ("path_dof.p3f", p3d.ACCEL_BVH, 1),
+                                             ("path_balls_low.p3f", p3d.ACCEL_BVH, 0)])
+def test_path_tracer(scene, accel, dof):
+    """Radiance (main.cpp:313-516): diffuse + NEE, mirror, dielectric (both-branch and Russian
+    roulette), RR termination; same RNG streams and detmath on both sides.  The kernel sums
+    radiance outermost-first, the oracle innermost-first: tolerance, not bit equality."""
+    dev, sc = _pair(scene_path(scene), res=(96, 96))
+    cfg = p3d.pathtrace_config(accel=accel, spp_sqrt=4, max_depth=20, dof=dof, seed=0x5EED, collect_stats=1)
+    rgb, hit, st = dev.render(cfg)
+    o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+    assert (hit == o_hit).all()
+    scale = max(1.0, float(np.abs(o_rgb).max()))
+    assert np.abs(rgb - o_rgb).max() <= TOL * scale
+    # identical paths: every ray class and every test count agrees exactly
+    for k in ("rays_primary", "rays_bounce", "rays_light", "node_tests", "sphere_tests", "tri_tests", "shaded_hits"):
+        assert getattr(st, k) == getattr(o_st, k), k
+
+
+@pytest.mark.parametrize("accel", [p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH])
+def test_batched_trace_queries(accel, tri5k_path):
+    """p3d_trace_closest / p3d_trace_any = BVH::intersect_bvh / bool_intersect_bvh, Grid::Traverse x2
+    and the brute-force loops, on random rays incl. axis-parallel and unnormalised directions."""
+    rng = np.random.default_rng(5)
+    for scene in (scene_path("balls_low.p3f"), tri5k_path, scene_path("path_glass.p3f")):
+        dev, sc = _pair(scene)
+        n = 4096
+        o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+        d = rng.standard_normal((n, 3)).astype(np.float32)
+        d[:64, 0] = 0.0          # axis-parallel: 1/0 = inf in the slab test
+        d[64:128, 1:] = 0.0
+        d[128:1024] *= rng.uniform(0.2, 5, (896, 1)).astype(np.float32)   # unnormalised (Q8)
+        hit, hp = dev.trace_closest(accel, o, d)
+        o_hit, _, o_hp = sc.trace_closest(accel, o, d)
+        assert (hit == o_hit).all()
+        m = hit >= 0
+        assert (hp[m].view(np.uint32) == o_hp[m].view(np.uint32)).all()
+        occ = dev.trace_any(accel, o, d)
+        assert (occ == sc.trace_any(accel, o, d)).all()
+
+
+def test_stripe_sharding_is_bit_invariant():
+    """Multi-GPU partition: any rank count / stripe height gives the same bits."""
+    dev, _ = _pair(scene_path("balls_low.p3f"), res=(128, 128), grid=False)
+    cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=3)
+    full, full_hit, _ = dev.render(cfg)
+    for world, sh in ((2, 8), (4, 16), (8, 16), (2, 4)):
+        out = np.zeros_like(full)
+        out_hit = np.zeros_like(full_hit)
+        for rank in range(world):
+            t = p3d.stripe_tile((128, 128), rank, world, sh)
+            rgb, hit, _ = dev.render(cfg, tile=t)
+            rows = p3d.stripe_rows((128, 128), rank, world, sh)
+            out[rows] = rgb
+            out_hit[rows] = hit
+        assert (out.view(np.uint32) == full.view(np.uint32)).all() and (out_hit == full_hit).all()
+    # sub-rectangle
+    t = p3d.Tile(40, 24, 50, 33, 0, 1)
+    rgb, hit, _ = dev.render(cfg, tile=t)
+    assert (rgb.view(np.uint32) == full[24:57, 40:90].view(np.uint32)).all()
+
+
+def test_rgb8_and_gamma():
+    dev, sc = _pair(scene_path("balls_low.p3f"), res=(96, 96), grid=False)
+    for gamma in (1.0, 2.2):
+        cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=2, gamma=gamma)
+        rgb, hit, rgb8, _ = dev.render(cfg, want_rgb8=True)
+        _, _, o8, _ = sc.render(oracle_cfg_like(cfg), want_rgb8=True)
+        assert np.abs(rgb8.astype(int) - o8.astype(int)).max() <= (0 if gamma == 1.0 else 1)
+
+
+def test_errors_are_reported_not_swallowed():
+    hs = p3d.HostScene(scene_path("balls_low.p3f"))
+    dev = p3d.DeviceScene(hs, bvh=False, grid=False)
+    with pytest.raises(p3d.P3DError) as e:
+        dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=1))
+    assert e.value.code == -1
+    with pytest.raises(p3d.P3DError):
+        dev.render(p3d.whitted_config(accel=p3d.ACCEL_NONE, max_depth=1), tile=p3d.Tile(0, 0, 4096, 8, 0, 1))
+    with pytest.raises(p3d.P3DError):
+        p3d.HostScene("/nonexistent.p3f")
+
+
+def test_full_size_cfg2_matches_reference_frame():
+    """BASELINE configs[1] at full size: 1024x1024, depth 4, BVH.  Ray counts must equal the
+    reference's (4 944 908 = 1 048 576 + 3 600 366 + 295 966) and the frame must
+    be within 1e-4 of the reference's own frame (tests/golden/survey_probe/cfg2_bvh)."""
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "survey_probe", "cfg2_bvh.npz"))
+    dev, _ = _pair(scene_path("balls_low.p3f"), res=(1024, 1024), grid=False)
+    rgb, hit, st = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, collect_stats=1))
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.rays_refract) == (1048576, 3600366, 295966, 0)
+    assert np.abs(rgb[::8, ::8] - g["sub8"]).max() <= TOL
+    for (x0, y0), crop in zip(g["crop_xy"], g["crops"]):
+        assert np.abs(rgb[y0:y0 + 64, x0:x0 + 64] - crop).max() <= TOL
+    assert np.abs(rgb.astype(np.float64).sum((0, 1)) - g["chan_sum"]).max() < 0.05
+
+
+def test_full_size_tri100k_matches_reference_frame(tri100k_path):
+    """The 100k-triangle scene at the survey's 512x512, depth 6: triangles never re-normalise
+    the ray, so here the kernel must reproduce the reference frame BIT FOR BIT."""
+    import hashlib
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "survey_probe", "tri100k_bvh_d6.npz"))
+    dev, _ = _pair(tri100k_path, grid=False)
+    rgb, hit, st = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=6, collect_stats=1))
+    assert st.rays == 2887776
+    assert np.abs(rgb[::8, ::8] - g["sub8"]).max() <= 2e-6
+    assert np.abs(rgb.astype(np.float64).sum((0, 1)) - g["chan_sum"]).max() < 0.05
