@@ -18,7 +18,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libp3d.so")
+LIB_PATH = os.environ.get("P3D_LIB") or os.path.join(HERE, "libp3d.so")  # P3D_LIB: kernel-variant experiments
 
 ACCEL_NONE, ACCEL_GRID, ACCEL_BVH = 0, 1, 2
 WHITTED, PATHTRACE = 0, 1

@@ -14,6 +14,11 @@
 #include "device_core.hpp"
 #include "p3d.h"
 
+// minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ arg)
+#ifndef P3D_WHITTED_WAVES
+#define P3D_WHITTED_WAVES 2
+#endif
+
 namespace p3d {
 
 struct RenderParams {
@@ -29,7 +34,7 @@ struct RenderParams {
   uint64_t seed;
   // tile
   int32_t x0, y0, w, h, stripe_h, stripe_stride;
-  uint32_t tiles_x, tiles_y, tiles_per_xcd;
+  uint32_t tiles_x, tiles_y, xcd_chunk;
   // outputs (device memory, any may be null)
   float* rgb;
   int32_t* hit_id;
@@ -58,13 +63,17 @@ __device__ __forceinline__ void stage_scene(DevScene& sc, const RenderParams& P,
   }
 }
 
-// XCD-aware block -> tile map: workgroups are dealt round-robin over the 8 XCDs, so blocks
-// b, b+8, b+16, ... share an L2.  Give each XCD one contiguous band of 8x8 tiles, so the
-// BVH nodes a band touches stay in that XCD's 4 MiB L2 (matters for the 8.8 MB scene).
+// XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs, so blocks
+// b, b+8, b+16, ... share an L2.  Tiles are grouped into chunks of `xcd_chunk` consecutive
+// 8x8 tiles (one tile row of the frame for big scenes) and chunks are dealt to XCDs round-
+// robin: each XCD's L2 sees spatially coherent rays (matters for the 8.8 MB scene, which
+// does not fit one 4 MiB L2) while expensive and cheap image regions are still spread over
+// all XCDs.  xcd_chunk = 1 is the identity map (LDS-staged scenes have no L2 working set).
 __device__ __forceinline__ bool tile_of_block(const RenderParams& P, uint32_t& tx, uint32_t& ty) {
   const uint32_t b = blockIdx.x;
-  const uint32_t tile = (b & 7u) * P.tiles_per_xcd + (b >> 3);
-  if ((b >> 3) >= P.tiles_per_xcd || tile >= P.tiles_x * P.tiles_y) return false;
+  const uint32_t j = b >> 3;
+  const uint32_t tile = ((j / P.xcd_chunk) * 8 + (b & 7u)) * P.xcd_chunk + (j % P.xcd_chunk);
+  if (tile >= P.tiles_x * P.tiles_y) return false;
   tx = tile % P.tiles_x;
   ty = tile / P.tiles_x;
   return true;
@@ -133,7 +142,7 @@ __device__ __forceinline__ void make_primary(const RenderParams& P, const DevCam
 // Whitted megakernel
 // ---------------------------------------------------------------------------
 template <int ACCEL, bool LDS, bool STATS>
-__global__ void __launch_bounds__(kBlock) whitted_kernel(const RenderParams P) {
+__global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(const RenderParams P) {
   extern __shared__ float4 smem[];
   uint32_t tx, ty;
   if (!tile_of_block(P, tx, ty)) return;

@@ -328,9 +328,12 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   if (tile->stripe_h > 0 && sh % 8 == 0 && bands_per_launch >= (uint32_t)(sh / 8))
     bands_per_launch = (bands_per_launch / (sh / 8)) * (sh / 8);  // chunks start on a stripe boundary
   bands_per_launch = std::min(bands_per_launch, total_bands);
-  const uint32_t max_tiles = tiles_x * bands_per_launch;
-  const uint32_t max_per_xcd = (max_tiles + 7) / 8;
-  const uint32_t max_threads = max_per_xcd * 8 * kBlock;
+  const uint32_t xcd_chunk = lds_scene ? 1u : tiles_x;
+  auto blocks_for = [&](uint32_t ntiles) {  // grid covering ntiles under the chunked XCD map
+    const uint32_t groups = (ntiles + 8 * xcd_chunk - 1) / (8 * xcd_chunk);
+    return groups * 8 * xcd_chunk;
+  };
+  const uint32_t max_threads = blocks_for(tiles_x * bands_per_launch) * kBlock;
   const uint32_t levels = pt ? 0 : (uint32_t)cfg->max_depth;
   if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * max_threads * sizeof(float4)))) return rc;
   if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)spill_entries * max_threads * sizeof(uint2)))) return rc;
@@ -356,9 +359,8 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       P.y0 = tile->y0 + row0;
     }
     P.tiles_x = tiles_x; P.tiles_y = nb;
-    const uint32_t ntiles = tiles_x * nb;
-    P.tiles_per_xcd = (ntiles + 7) / 8;
-    const uint32_t blocks = P.tiles_per_xcd * 8;
+    P.xcd_chunk = xcd_chunk;
+    const uint32_t blocks = blocks_for(tiles_x * nb);
     P.level_stride = blocks * kBlock;
     const size_t off = (size_t)row0 * tile->w;
     P.rgb = d_rgb ? d_rgb + 3 * off : nullptr;
