@@ -141,7 +141,7 @@ __device__ __forceinline__ void make_primary(const RenderParams& P, const DevCam
 // ---------------------------------------------------------------------------
 // Whitted megakernel
 // ---------------------------------------------------------------------------
-template <int ACCEL, bool LDS, bool STATS>
+template <int ACCEL, bool LDS, bool STATS, bool AA>
 __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(const RenderParams P) {
   extern __shared__ float4 smem[];
   uint32_t tx, ty;
@@ -166,15 +166,16 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
     const int x = P.x0 + c;
     const int y = P.y0 + (r / sh) * sh * ss + (r % sh);
     const uint32_t gid = blockIdx.x * kBlock + lane;
-    const int SPP = P.antialiasing ? (int)P.spp_sqrt : 1;
+    const int SPP = AA ? (int)P.spp_sqrt : 1;
     ct.add(kPixels);
 
     F3 color = f3(0, 0, 0);
     int first_hit = -1;
     Rng rng;
+    rng.state = 0; rng.inc = 1;
     for (int si = 0; si < SPP; ++si) {
       for (int sj = 0; sj < SPP; ++sj) {
-        rng.seed_stream(P.seed, (uint32_t)(y * sc.cam.res_x + x), (uint32_t)(si * SPP + sj));
+        if (AA) rng.seed_stream(P.seed, (uint32_t)(y * sc.cam.res_x + x), (uint32_t)(si * SPP + sj));
         st.sp = 0;  // hit_stack starts empty at every primary sample (DESIGN.md "Sequential state")
         F3 o, d;
         make_primary(P, sc.cam, x, y, si, sj, rng, o, d);
@@ -197,16 +198,16 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
             break;
           }
           ct.add(kShadedHits);
-          const uint32_t m = geom_material(g);
-          const float4 m0 = sc.mats[4 * m], m1 = sc.mats[4 * m + 1], m2 = sc.mats[4 * m + 2];
+          const uint32_t m = geom_material(g);  // material rows are re-read where used, not carried
           const F3 intercept = offset_intersection(Pn, get_normal(g, sc.normals, Pn));  // main.cpp:165
           F3 norm = get_normal(g, sc.normals, intercept);                               // main.cpp:167
           F3 diff = f3(0, 0, 0), spec = f3(0, 0, 0);
           if (!inside) {  // main.cpp:172-227
             for (uint32_t li = 0; li < sc.n_lights; ++li) {
-              const float4 l0 = sc.lights[2 * li], l1 = sc.lights[2 * li + 1];
+              // the light index is wave-uniform: read through the scalar cache (s_load), not LDS
+              const float4 l0 = P.sc.lights[2 * li];
               F3 lpos = xyz(l0);
-              if (P.antialiasing && P.soft_shadows) {  // main.cpp:180-186 (g++ draws y first)
+              if (AA && P.soft_shadows) {  // main.cpp:180-186 (g++ draws y first)
                 const float jy = rng.rand_float();
                 const float jx = rng.rand_float();
                 lpos = f3(l0.x + P.light_side * (si + jx) / SPP, l0.y + P.light_side * (sj + jy) / SPP, l0.z);
@@ -218,16 +219,21 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
               const bool shadowed = any_hit<ACCEL>(sc, st, feeler, ct);
               const F3 blinn = normalized((l_dir + get_direction(ray) * -1.0f) / 2);
               if (!shadowed) {  // main.cpp:222-225: max() and pow() evaluate in double
+                const float4 l1 = P.sc.lights[2 * li + 1];
+                const float4 m0 = sc.mats[4 * m], m1 = sc.mats[4 * m + 1];
+                const float shine = sc.mats[4 * m + 2].x;
                 const float nl = dot(norm, l_dir);
                 const float bn = dot(blinn, norm);
                 const float kd = (0.0f > nl) ? 0.0f : nl;
                 const float kb = (0.0f > bn) ? 0.0f : bn;
                 diff = diff + (xyz(l1) * xyz(m0)) * kd;
-                spec = spec + (xyz(l1) * xyz(m1)) * (float)pow((double)kb, (double)m2.x);
+                spec = spec + (xyz(l1) * xyz(m1)) * (float)pow_spec((double)kb, (double)shine);
               }
             }
           }
-          const F3 col = diff * m0.w + spec * m1.w;  // main.cpp:232
+          const float4 m2 = sc.mats[4 * m + 2];
+          const float mKd = sc.mats[4 * m].w, mKs = sc.mats[4 * m + 1].w;
+          const F3 col = diff * mKd + spec * mKs;  // main.cpp:232
           if (depth <= 0) {
             result = clamp01(col);
             break;
@@ -247,7 +253,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
               const F3 b = get_direction(ray);
               const F3 a = norm * dot(get_direction(ray) * -1.0f, norm) * 2;
               ray_set(child, intercept, a + b);
-              weight = m1.w;
+              weight = mKs;
               have_child = true;
               ct.add(kRaysReflect);
             }
@@ -287,7 +293,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
         color = color + result;
       }
     }
-    if (P.antialiasing) color = color / (float)(SPP * SPP);  // main.cpp:800
+    if (AA) color = color / (float)(SPP * SPP);  // main.cpp:800
 
     const size_t k = (size_t)r * P.w + c;
     if (P.rgb) {

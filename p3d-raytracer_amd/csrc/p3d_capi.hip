@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -105,8 +106,10 @@ int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
       return fail(P3D_ERR_INVALID, "p3d_scene_create: inconsistent BVH arrays");
     for (uint32_t i = 0; i < d->n_bvh_nodes; ++i) {
       const p3d_bvh_node& n = d->bvh_nodes[i];
+      if (n.index > 0x0fffffffu) return fail(P3D_ERR_CAPACITY, "p3d_scene_create: BVH index exceeds 2^28");
       if (n.count_leaf & P3D_BVH_LEAF) {
         const uint64_t cnt = n.count_leaf & ~P3D_BVH_LEAF;
+        if (cnt > 7) return fail(P3D_ERR_CAPACITY, "p3d_scene_create: BVH leaf with more than 7 objects (the reference's Threshold is 2)");
         if ((uint64_t)n.index + cnt > d->n_bvh_prim_index) return fail(P3D_ERR_INVALID, "p3d_scene_create: BVH leaf range out of bounds");
       } else if ((uint64_t)n.index + 1 >= d->n_bvh_nodes || n.index <= i) {
         return fail(P3D_ERR_INVALID, "p3d_scene_create: BVH child index out of bounds");
@@ -148,11 +151,11 @@ int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
   s->off_nodes = (uint32_t)blob.size();
   for (uint32_t i = 0; i < d->n_bvh_nodes; ++i) {
     const p3d_bvh_node& n = d->bvh_nodes[i];
-    float idx, cl;
-    std::memcpy(&idx, &n.index, 4);
-    std::memcpy(&cl, &n.count_leaf, 4);
-    blob.push_back(make_float4(n.bmin[0], n.bmin[1], n.bmin[2], idx));
-    blob.push_back(make_float4(n.bmax[0], n.bmax[1], n.bmax[2], cl));
+    const uint32_t desc = (n.count_leaf & P3D_BVH_LEAF) ? (kDescLeaf | ((n.count_leaf & 7u) << 28) | n.index) : n.index;
+    float descf;
+    std::memcpy(&descf, &desc, 4);
+    blob.push_back(make_float4(n.bmin[0], n.bmin[1], n.bmin[2], descf));
+    blob.push_back(make_float4(n.bmax[0], n.bmax[1], n.bmax[2], 0.f));
   }
   s->off_bgeom = (uint32_t)blob.size();
   for (uint32_t i = 0; i < d->n_bvh_prim_index; ++i) {
@@ -244,15 +247,16 @@ int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
 namespace {
 
 template <int ACCEL, bool LDS, bool STATS>
-hipError_t launch_one(bool pt, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+hipError_t launch_one(bool pt, bool aa, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
   if (pt) hipLaunchKernelGGL((pt_kernel<ACCEL, LDS, STATS>), dim3(blocks), dim3(kBlock), lds, st, P);
-  else hipLaunchKernelGGL((whitted_kernel<ACCEL, LDS, STATS>), dim3(blocks), dim3(kBlock), lds, st, P);
+  else if (aa) hipLaunchKernelGGL((whitted_kernel<ACCEL, LDS, STATS, true>), dim3(blocks), dim3(kBlock), lds, st, P);
+  else hipLaunchKernelGGL((whitted_kernel<ACCEL, LDS, STATS, false>), dim3(blocks), dim3(kBlock), lds, st, P);
   return hipGetLastError();
 }
 template <int ACCEL>
-hipError_t launch_accel(bool pt, bool lds_scene, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
-  if (lds_scene) return stats ? launch_one<ACCEL, true, true>(pt, P, blocks, lds, st) : launch_one<ACCEL, true, false>(pt, P, blocks, lds, st);
-  return stats ? launch_one<ACCEL, false, true>(pt, P, blocks, lds, st) : launch_one<ACCEL, false, false>(pt, P, blocks, lds, st);
+hipError_t launch_accel(bool pt, bool aa, bool lds_scene, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+  if (lds_scene) return stats ? launch_one<ACCEL, true, true>(pt, aa, P, blocks, lds, st) : launch_one<ACCEL, true, false>(pt, aa, P, blocks, lds, st);
+  return stats ? launch_one<ACCEL, false, true>(pt, aa, P, blocks, lds, st) : launch_one<ACCEL, false, false>(pt, aa, P, blocks, lds, st);
 }
 
 int check_accel(const p3d_scene* s, uint32_t accel) {
@@ -268,6 +272,33 @@ uint32_t stack_bound(const p3d_scene* s, uint32_t accel, bool whitted) {
   if (accel != P3D_ACCEL_BVH) return 1;
   const uint32_t per = s->bvh_max_depth > 1 ? s->bvh_max_depth - 1 : 1;
   return whitted ? (s->dev.n_lights + 1) * per : per;
+}
+
+
+int finish_stats(p3d_scene* s, hipStream_t st, p3d_stats* stats) {
+  P3D_HIP(hipEventRecord(s->ev1, st));
+  P3D_HIP(hipEventSynchronize(s->ev1));
+  float ms = 0;
+  P3D_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+  unsigned long long h[kNumStats];
+  P3D_HIP(hipMemcpy(h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+  std::memset(stats, 0, sizeof(*stats));
+  stats->kernel_ms = ms;
+  stats->rays_primary = h[kRaysPrimary]; stats->rays_shadow = h[kRaysShadow]; stats->rays_reflect = h[kRaysReflect];
+  stats->rays_refract = h[kRaysRefract]; stats->rays_bounce = h[kRaysBounce]; stats->rays_light = h[kRaysLight];
+  stats->node_tests = h[kNodeTests]; stats->sphere_tests = h[kSphereTests]; stats->tri_tests = h[kTriTests];
+  stats->box_tests = h[kBoxTests]; stats->plane_tests = h[kPlaneTests]; stats->shaded_hits = h[kShadedHits];
+  stats->pixels = h[kPixels]; stats->max_stack = h[kMaxStack];
+  return P3D_OK;
+}
+
+bool getenv_flag(const char* name) {
+  const char* v = std::getenv(name);
+  return v && *v && *v != '0';
+}
+int getenv_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return (v && *v) ? std::atoi(v) : dflt;
 }
 
 }  // namespace
@@ -368,27 +399,13 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     P.rgb8 = d_rgb8 ? d_rgb8 + 3 * off : nullptr;
     hipError_t e;
     switch (cfg->accel) {
-      case P3D_ACCEL_BVH: e = launch_accel<P3D_ACCEL_BVH>(pt, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
-      case P3D_ACCEL_GRID: e = launch_accel<P3D_ACCEL_GRID>(pt, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
-      default: e = launch_accel<P3D_ACCEL_NONE>(pt, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+      case P3D_ACCEL_BVH: e = launch_accel<P3D_ACCEL_BVH>(pt, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+      case P3D_ACCEL_GRID: e = launch_accel<P3D_ACCEL_GRID>(pt, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+      default: e = launch_accel<P3D_ACCEL_NONE>(pt, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
     }
     if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
   }
-  if (stats) {
-    P3D_HIP(hipEventRecord(s->ev1, st));
-    P3D_HIP(hipEventSynchronize(s->ev1));
-    float ms = 0;
-    P3D_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-    unsigned long long h[kNumStats];
-    P3D_HIP(hipMemcpy(h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
-    std::memset(stats, 0, sizeof(*stats));
-    stats->kernel_ms = ms;
-    stats->rays_primary = h[kRaysPrimary]; stats->rays_shadow = h[kRaysShadow]; stats->rays_reflect = h[kRaysReflect];
-    stats->rays_refract = h[kRaysRefract]; stats->rays_bounce = h[kRaysBounce]; stats->rays_light = h[kRaysLight];
-    stats->node_tests = h[kNodeTests]; stats->sphere_tests = h[kSphereTests]; stats->tri_tests = h[kTriTests];
-    stats->box_tests = h[kBoxTests]; stats->plane_tests = h[kPlaneTests]; stats->shaded_hits = h[kShadedHits];
-    stats->pixels = h[kPixels]; stats->max_stack = h[kMaxStack];
-  }
+  if (stats) return finish_stats(s, st, stats);
   return P3D_OK;
 }
 
