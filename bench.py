@@ -95,12 +95,7 @@ def main():
     frame_hit = torch.empty((res, res), dtype=torch.int32, device="cuda") if rank == 0 and world > 1 else None
 
     def assemble(slot):
-        # rows of stripe s of rank r sit at frame rows (s*world + r)*stripe_h ..: stack on a new axis
-        n_str = res // (stripe_h * world)
-        parts = [g[: n_local * 12].view(torch.float32).view(n_str, stripe_h, res, 3) for g in gathered[slot]]
-        frame_rgb.view(n_str, world, stripe_h, res, 3).copy_(torch.stack(parts, dim=1))
-        hits = [g[n_local * 12:].view(torch.int32).view(n_str, stripe_h, res) for g in gathered[slot]]
-        frame_hit.view(n_str, world, stripe_h, res).copy_(torch.stack(hits, dim=1))
+        p3d.assemble_frame(gathered[slot], (res, res), world, stripe_h, frame_rgb, frame_hit)
 
     ev_pairs = []
 
@@ -120,7 +115,8 @@ def main():
             e1.record(stream)
             ev_pairs.append((e0, e1))
         if world > 1:
-            handles[slot] = dist.gather(b, gathered[slot] if rank == 0 else None, dst=0, async_op=True)
+            handles[slot], _ = p3d.gather_frame(b, (res, res), rank, world, stripe_h, 0,
+                                                gathered[slot] if rank == 0 else None, async_op=True)
 
     def drain():
         for slot in (0, 1):

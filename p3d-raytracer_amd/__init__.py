@@ -237,7 +237,7 @@ class HostScene:
         d = self.desc(bvh, grid)
         out = dict(n_prims=d.n_prims, n_materials=d.n_materials, n_lights=d.n_lights,
                    res=(d.camera.res_x, d.camera.res_y), background=np.array(d.background[:], np.float32))
-        prims = [d.prims[i] for i in range(d.n_prims)]
+        prims = [d.prims[i] for i in range(d.n_prims)] if d.n_prims else []
         out["prim_v"] = np.array([list(p.v) for p in prims], np.float32).reshape(-1, 9)
         out["prim_type"] = np.array([p.type for p in prims], np.uint32)
         out["prim_material"] = np.array([p.material for p in prims], np.uint32)
@@ -261,7 +261,8 @@ class HostScene:
             out["bvh_index"] = buf[:, 3].copy()
             out["bvh_bmax"] = buf[:, 4:7].view(np.float32)
             out["bvh_count_leaf"] = buf[:, 7].copy()
-            out["bvh_order"] = np.ctypeslib.as_array(d.bvh_prim_index, shape=(d.n_bvh_prim_index,)).copy()
+            out["bvh_order"] = (np.ctypeslib.as_array(d.bvh_prim_index, shape=(d.n_bvh_prim_index,)).copy()
+                                if d.n_bvh_prim_index else np.zeros(0, np.uint32))
             out["bvh_max_depth"] = d.bvh_max_depth
         if grid:
             g = d.grid
@@ -353,3 +354,39 @@ def stripe_rows(res, rank, world, stripe_h=16):
     t = stripe_tile(res, rank, world, stripe_h)
     r = np.arange(t.h)
     return t.y0 + (r // stripe_h) * stripe_h * world + (r % stripe_h)
+
+
+# ---- multi-GPU helpers (one process per GPU; torch.distributed moves the bytes) ----
+def packed_bytes(n_pixels):
+    """Per-rank framebuffer layout used for the gather: [rgb float32 x3 | hit int32] = 16 B/pixel."""
+    return n_pixels * 16
+
+
+def assemble_frame(gathered, res, world, stripe_h, frame_rgb=None, frame_hit=None):
+    """De-interleave the per-rank stripe buffers (torch uint8 tensors laid out as packed_bytes)
+    into the full frame: stripe s of rank r holds frame rows (s*world + r)*stripe_h ... +stripe_h."""
+    import torch
+    rx, ry = res
+    n_str = ry // (stripe_h * world)
+    n_local = rx * (ry // world)
+    dev = gathered[0].device
+    if frame_rgb is None:
+        frame_rgb = torch.empty((ry, rx, 3), dtype=torch.float32, device=dev)
+    if frame_hit is None:
+        frame_hit = torch.empty((ry, rx), dtype=torch.int32, device=dev)
+    parts = [g[: n_local * 12].view(torch.float32).view(n_str, stripe_h, rx, 3) for g in gathered]
+    frame_rgb.view(n_str, world, stripe_h, rx, 3).copy_(torch.stack(parts, dim=1))
+    hits = [g[n_local * 12: n_local * 16].view(torch.int32).view(n_str, stripe_h, rx) for g in gathered]
+    frame_hit.view(n_str, world, stripe_h, rx).copy_(torch.stack(hits, dim=1))
+    return frame_rgb, frame_hit
+
+
+def gather_frame(local_buf, res, rank, world, stripe_h, dst=0, gathered=None, async_op=False):
+    """One collective per frame: every rank's packed stripe buffer to rank `dst` (RCCL on GPUs,
+    gloo in the CPU tests).  Returns (work handle or None, gather list or None)."""
+    import torch
+    import torch.distributed as dist
+    if rank == dst and gathered is None:
+        gathered = [torch.empty_like(local_buf) for _ in range(world)]
+    work = dist.gather(local_buf, gathered if rank == dst else None, dst=dst, async_op=async_op)
+    return work, gathered

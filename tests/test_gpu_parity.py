@@ -254,3 +254,18 @@ def test_full_size_tri100k_matches_reference_frame(tri100k_path):
     assert st.rays == 2887776
     assert np.abs(rgb[::8, ::8] - g["sub8"]).max() <= 2e-6
     assert np.abs(rgb.astype(np.float64).sum((0, 1)) - g["chan_sum"]).max() < 0.05
+
+
+@pytest.mark.parametrize("lens", [None, (10.0, 1.0)])
+def test_cornell_path_tracer(lens):
+    """BASELINE configs[2]/[4] scene (scenes/cornell.p3f) at reduced size: 64x64, 16 spp; with the
+    thin-lens sampler (aperture 10, SAMPLE_DISK) for the configs[4] variant."""
+    from conftest import ROOT
+    dev, sc = _pair(os.path.join(ROOT, "scenes", "cornell.p3f"), res=(64, 64), grid=False, lens=lens)
+    cfg = p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=4, max_depth=20, dof=1 if lens else 0, seed=0x5EED,
+                               collect_stats=1)
+    rgb, hit, st = dev.render(cfg)
+    o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+    assert (hit == o_hit).all()
+    assert np.abs(rgb - o_rgb).max() <= TOL * max(1.0, float(np.abs(o_rgb).max()))
+    assert (st.rays_primary, st.rays_bounce, st.rays_light) == (o_st.rays_primary, o_st.rays_bounce, o_st.rays_light)

@@ -1,0 +1,141 @@
+"""CPU tests of the product's HOST side (no GPU needed): the C-ABI library loads and exports
+every symbol include/p3d.h declares; the .p3f loader, BVH builder and grid builder inside
+libp3d.so produce bit-for-bit what the oracle's independent restatement produces."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import p3d_amd as p3d
+from conftest import ROOT, SCENES, scene_path
+from oracle import binding as ob
+
+ALL_SCENES = sorted(f for f in os.listdir(SCENES) if f.endswith(".p3f"))
+
+
+def u32(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "p3d.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(p3d_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(p3d.EXPORTS), declared ^ set(p3d.EXPORTS)
+    lib = p3d.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.p3d_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(p3d.Prim) == 96 and C.sizeof(p3d.Material) == 64 and C.sizeof(p3d.Light) == 32
+    assert C.sizeof(p3d.Camera) == 80 and C.sizeof(p3d.BvhNode) == 32
+    assert C.sizeof(p3d.Config) == 56 and C.sizeof(p3d.Tile) == 24 and C.sizeof(p3d.Stats) == 15 * 8
+
+
+def test_config_default_is_constants_h():
+    c = p3d.default_config()
+    assert (c.integrator, c.accel, c.max_depth, c.spp_sqrt) == (p3d.PATHTRACE, p3d.ACCEL_BVH, 20, 20)  # constants.h:6,12,36,44
+    assert (c.antialiasing, c.depth_of_field, c.sample_disk, c.soft_shadows, c.sample_mode) == (1, 1, 1, 0, 0)
+    assert (c.light_side, c.gamma) == (0.5, 1.0)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    if p3d.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    hs = p3d.HostScene(scene_path("balls_low.p3f"))
+    with pytest.raises(p3d.P3DError) as e:
+        p3d.DeviceScene(hs)
+    assert e.value.code == -2  # P3D_ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("scene", ALL_SCENES)
+@pytest.mark.parametrize("legacy", [False, True])
+def test_loader_and_builders_match_oracle(scene, legacy):
+    hs = p3d.HostScene(scene_path(scene), legacy_f11=legacy)
+    sc = ob.Scene(scene_path(scene), legacy_f11=legacy)
+    cnt = sc.counts()
+    try:
+        a = hs.arrays(bvh=True, grid=cnt["objects"] > 0)
+    except p3d.P3DError:
+        # objects before the first `f`: neither side can render (the reference would null-deref)
+        assert any(sc.object(i)["material"] < 0 for i in range(cnt["objects"]))
+        return
+    assert (a["n_prims"], a["n_lights"], a["n_materials"]) == (cnt["objects"], cnt["lights"], cnt["materials"])
+    for i in range(cnt["objects"]):
+        o = sc.object(i)
+        assert a["prim_type"][i] == o["type"] and a["prim_material"][i] == o["material"]
+        assert (u32(a["prim_v"][i]) == u32(o["v"])).all()
+        assert (u32(a["prim_bmin"][i]) == u32(o["bmin"])).all() and (u32(a["prim_bmax"][i]) == u32(o["bmax"])).all()
+        if o["type"] == 1:
+            assert (u32(a["prim_n"][i]) == u32(o["n"])).all()
+    for i in range(cnt["materials"]):
+        assert (u32(a["materials"][i][:15]) == u32(sc.material(i)[:15])).all()
+    for i in range(cnt["lights"]):
+        p, c = sc.light(i)
+        assert (u32(a["lights"][i]) == u32(np.concatenate([p, c]))).all()
+    if cnt["has_camera"]:
+        cam = sc.camera()
+        for k in ("eye", "u", "v", "n"):
+            assert (u32(a["camera"][k]) == u32(cam[k])).all()
+        for k in ("w", "h", "plane_dist", "focal_ratio", "aperture"):
+            assert np.float32(a["camera"][k]).view(np.uint32) == np.float32(cam[k]).view(np.uint32)
+    assert (u32(a["background"]) == u32(sc.background())).all()
+    # BVH: same nodes in the same order, same permutation (bvh.cpp:89-196)
+    o = sc.bvh_nodes()
+    assert len(a["bvh_index"]) == len(o["index"])
+    assert (u32(a["bvh_bmin"]) == u32(o["bmin"])).all() and (u32(a["bvh_bmax"]) == u32(o["bmax"])).all()
+    assert (a["bvh_index"] == o["index"]).all() and (a["bvh_order"] == o["order"]).all()
+    assert (((a["bvh_count_leaf"] >> 31) & 1) == o["leaf"]).all()
+    leaf = o["leaf"] == 1
+    assert ((a["bvh_count_leaf"][leaf] & 0x7fffffff) == o["n_objs"][leaf]).all()
+    assert a["bvh_max_depth"] == sc.bvh_info()["max_depth"]
+    if cnt["objects"] > 0:  # grid.cpp:3-68
+        g = sc.grid()
+        assert tuple(a["grid_n"]) == tuple(int(v) for v in g["n"])
+        assert (u32(a["grid_bmin"]) == u32(g["bmin"])).all() and (u32(a["grid_bmax"]) == u32(g["bmax"])).all()
+        assert (a["grid_cell_start"] == g["cell_start"]).all() and (a["grid_cell_items"] == g["cell_items"]).all()
+
+
+def test_big_bvh_matches_oracle_and_reference_counts(tri100k_path):
+    hs = p3d.HostScene(tri100k_path)
+    a = hs.arrays(bvh=True)
+    sc = ob.Scene(tri100k_path)
+    o = sc.bvh_nodes()
+    assert len(a["bvh_index"]) == 125701 and a["bvh_max_depth"] == 21
+    assert (a["bvh_index"] == o["index"]).all() and (a["bvh_order"] == o["order"]).all()
+    assert (u32(a["bvh_bmin"]) == u32(o["bmin"])).all() and (u32(a["bvh_bmax"]) == u32(o["bmax"])).all()
+
+
+def test_camera_overrides_and_light_replication():
+    hs = p3d.HostScene(scene_path("path_dof.p3f"))
+    sc = ob.Scene(scene_path("path_dof.p3f"))
+    for h in (hs, sc):
+        h.set_resolution(640, 360)
+        h.set_lens(4.0, 1.25)
+    a = hs.arrays()
+    cam = sc.camera()
+    assert a["res"] == (640, 360)
+    for k in ("w", "h", "aperture", "focal_ratio"):
+        assert np.float32(a["camera"][k]).view(np.uint32) == np.float32(cam[k]).view(np.uint32)
+    hs2 = p3d.HostScene(scene_path("balls_low.p3f"))
+    sc2 = ob.Scene(scene_path("balls_low.p3f"))
+    hs2.replicate_lights(4, 0.5)
+    sc2.replicate_lights(4, 0.5)
+    a2 = hs2.arrays()
+    assert a2["n_lights"] == 3 * 16 == sc2.counts()["lights"]
+    for i in range(a2["n_lights"]):
+        p, c = sc2.light(i)
+        assert (u32(a2["lights"][i]) == u32(np.concatenate([p, c]))).all()
+
+
+def test_loader_error_paths():
+    with pytest.raises(p3d.P3DError) as e:
+        p3d.HostScene("/no/such/scene.p3f")
+    assert e.value.code == -5
+    hs = p3d.HostScene(scene_path("balls_medium.p3f"))   # 11-number `f`: shipped parser stops, 0 objects
+    assert hs.arrays()["n_prims"] == 0 and hs.arrays()["n_lights"] == 3
+    assert p3d.HostScene(scene_path("balls_medium.p3f"), legacy_f11=True).arrays()["n_prims"] == 93
