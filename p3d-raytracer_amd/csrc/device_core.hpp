@@ -127,12 +127,17 @@ __device__ __forceinline__ double pow_spec(double x, double y) {
 struct RayS {
   F3 o, d, inv;
   bool settled;
+  bool odd_inv;  // some 1/d component is +-inf or NaN: the slab test can then produce NaNs (0 * inf)
 };
+__device__ __forceinline__ bool inv_is_odd(F3 inv) {
+  return !(fabsf(inv.x) < INFINITY) || !(fabsf(inv.y) < INFINITY) || !(fabsf(inv.z) < INFINITY);
+}
 __device__ __forceinline__ void ray_set(RayS& r, F3 o, F3 d) {
   r.o = o;
   r.d = d;
   r.inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   r.settled = false;
+  r.odd_inv = inv_is_odd(r.inv);
 }
 __device__ __forceinline__ F3 get_direction(RayS& r) {
   if (!r.settled) {
@@ -142,6 +147,7 @@ __device__ __forceinline__ F3 get_direction(RayS& r) {
     } else {
       r.d = n;
       r.inv = f3(1.0f / n.x, 1.0f / n.y, 1.0f / n.z);
+      r.odd_inv = inv_is_odd(r.inv);
     }
   }
   return r.d;
@@ -212,23 +218,44 @@ struct DevScene {
 // see DESIGN.md "Sequential state").  The first `cap` entries live in LDS; deeper entries
 // (rare: the worst case is (lights+1)*(tree depth-1), typical depth is a handful) spill to
 // a per-thread column of a global scratch array, so no launch ever has to be repeated.
+typedef __attribute__((address_space(3))) unsigned long long lds_uint2;  // explicit LDS pointer to one 8-byte entry: ds_read/write_b64, never flat_*
 struct Stack {
-  uint2* base;   // LDS: &stack[lane]; entry e at base[e * kBlock]
-  uint2* spill;  // global: &spill[thread]; entry cap+e at spill[e * spill_stride]
+  lds_uint2* base;  // LDS: &stack[lane]; entry e at base[e * kBlock]
+  uint2* spill;     // global: &spill[thread]; entry cap+e at spill[e * spill_stride]
   uint32_t spill_stride;
   int sp;
   int cap;
 };
-template <class CT>
+__device__ __forceinline__ lds_uint2* lds_stack_ptr(float4* smem_base, size_t float4_offset, uint32_t lane) {
+  return (lds_uint2*)(reinterpret_cast<unsigned long long*>(smem_base + float4_offset)) + lane;
+}
+// SPILL == false: the host guarantees cap >= worst-case height, every access is a plain
+// ds_read_b64 / ds_write_b64.  SPILL == true (deep trees): entries >= cap go to global memory.
+template <bool SPILL, class CT>
 __device__ __forceinline__ void push(Stack& s, uint32_t node, float t, CT& ct) {
   const uint2 e = make_uint2(node, __float_as_uint(t));
-  if (s.sp < s.cap) s.base[s.sp * kBlock] = e;
-  else s.spill[(size_t)(s.sp - s.cap) * s.spill_stride] = e;
+  if (!SPILL || s.sp < s.cap) {
+    lds_uint2* p = s.base + s.sp * kBlock;
+    *p = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
+  } else {
+    s.spill[(size_t)(s.sp - s.cap) * s.spill_stride] = e;
+  }
   ++s.sp;
   ct.stack_depth(s.sp);
 }
+template <bool SPILL>
 __device__ __forceinline__ uint2 stack_read(const Stack& s, int i) {
-  return (i < s.cap) ? s.base[i * kBlock] : s.spill[(size_t)(i - s.cap) * s.spill_stride];
+  uint2 e;
+  if (!SPILL || i < s.cap) {
+    const lds_uint2* p = s.base + i * kBlock;
+    const unsigned long long v = *p;
+    e = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+    if (SPILL) asm volatile("" : "+v"(e.x), "+v"(e.y));  // keep the two address spaces apart (no flat_load)
+  } else {
+    e = s.spill[(size_t)(i - s.cap) * s.spill_stride];
+    asm volatile("" : "+v"(e.x), "+v"(e.y));
+  }
+  return e;
 }
 
 struct Geom {
@@ -246,13 +273,24 @@ __device__ __forceinline__ uint32_t geom_material(const Geom& g) { return __floa
 __device__ __forceinline__ uint32_t geom_object(const Geom& g) { return __float_as_uint(g.c.z); }
 
 // boundingBox.cpp:44-98.  Raw direction; t0 < t1 strict; t1 > 0.0001 (double literal).
-__device__ __forceinline__ bool aabb_intercepts(F3 mn, F3 mx, const RayS& r, float& t) {
+// MAX3/MIN3 (scene.h:17-22) are select chains whose result depends on operand order when a
+// NaN is present (0 * inf at an axis-parallel ray touching a slab plane).  `all_finite` is a
+// WAVE-UNIFORM promise that no lane's 1/d has an inf/NaN component: then no NaN can arise,
+// the chains equal plain max/min and one v_max3_f32 / v_min3_f32 each replaces 12 compares
+// and selects (the sign of a zero result is never observable: only orderings of t matter).
+__device__ __forceinline__ bool aabb_intercepts(F3 mn, F3 mx, const RayS& r, float& t, bool all_finite) {
   const float a = r.inv.x, b = r.inv.y, c = r.inv.z;
   const float tx_min = ((a >= 0 ? mn.x : mx.x) - r.o.x) * a, tx_max = ((a >= 0 ? mx.x : mn.x) - r.o.x) * a;
   const float ty_min = ((b >= 0 ? mn.y : mx.y) - r.o.y) * b, ty_max = ((b >= 0 ? mx.y : mn.y) - r.o.y) * b;
   const float tz_min = ((c >= 0 ? mn.z : mx.z) - r.o.z) * c, tz_max = ((c >= 0 ? mx.z : mn.z) - r.o.z) * c;
-  const float t0 = max3_ref(tx_min, ty_min, tz_min);
-  const float t1 = min3_ref(tx_max, ty_max, tz_max);
+  float t0, t1;
+  if (all_finite) {
+    t0 = __builtin_fmaxf(__builtin_fmaxf(tx_min, ty_min), tz_min);
+    t1 = __builtin_fminf(__builtin_fminf(tx_max, ty_max), tz_max);
+  } else {
+    t0 = max3_ref(tx_min, ty_min, tz_min);
+    t1 = min3_ref(tx_max, ty_max, tz_max);
+  }
   t = (t0 < 0) ? t1 : t0;
   return (t0 < t1) && gt_1em4(t1);
 }
@@ -301,7 +339,7 @@ __device__ __forceinline__ bool intercepts(const Geom& g, RayS& ray, float& time
     return true;
   } else if (type == P3D_PRIM_BOX) {  // scene.cpp:215-227
     ct.add(kBoxTests);
-    return aabb_intercepts(f3(g.a.x, g.a.y, g.a.z), f3(g.a.w, g.b.x, g.b.y), ray, time);
+    return aabb_intercepts(f3(g.a.x, g.a.y, g.a.z), f3(g.a.w, g.b.x, g.b.y), ray, time, false);
   } else {  // plane, scene.cpp:116-137
     ct.add(kPlaneTests);
     const F3 PN = f3(g.a.x, g.a.y, g.a.z), A = f3(g.a.w, g.b.x, g.b.y);
@@ -353,13 +391,13 @@ __device__ __forceinline__ NodeRec load_node(const float4* nodes, uint32_t i) {
 
 // Closest hit.  `ray` is the traversal's private copy (bvh.cpp:198 takes Ray by value).
 // Returns the leaf slot of the hit (-1 = miss) and the hit point d*tmin + o (bvh.cpp:271).
-template <class CT>
+template <bool SPILL, class CT>
 __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_point, Geom& hit_geom, CT& ct) {
   float tmp, tmin = FLT_MAX;
   int hit = -1;
   NodeRec cur = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
-  if (!aabb_intercepts(xyz(cur.lo), xyz(cur.hi), ray, tmp)) return -1;  // stale entries stay (Q2)
+  if (!aabb_intercepts(xyz(cur.lo), xyz(cur.hi), ray, tmp, false)) return -1;  // stale entries stay (Q2)
   while (true) {
     const uint32_t desc = __float_as_uint(cur.lo.w), index = desc_index(desc);
     bool descended = false;
@@ -367,13 +405,14 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
       float l_t, r_t;
       ct.add(kNodeTests, 2);
-      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t);
-      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t);
+      const bool fin = !__any(ray.odd_inv);  // wave-uniform: may the slab tests use max3/min3?
+      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin);
+      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin);
       if (is_inside(xyz(l.lo), xyz(l.hi), ray.o)) l_t = 0;  // bvh.cpp:216-217
       if (is_inside(xyz(r.lo), xyz(r.hi), ray.o)) r_t = 0;
       if (l_hit && r_hit) {
-        if (l_t < r_t) { cur = l; push(st, index + 1, r_t, ct); }
-        else           { cur = r; push(st, index, l_t, ct); }  // ties go right (Q10)
+        if (l_t < r_t) { cur = l; push<SPILL>(st, index + 1, r_t, ct); }
+        else           { cur = r; push<SPILL>(st, index, l_t, ct); }  // ties go right (Q10)
         descended = true;
       } else if (l_hit) { cur = l; descended = true; }
       else if (r_hit)   { cur = r; descended = true; }
@@ -393,7 +432,7 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
     bool changed = false;
     while (st.sp > 0) {  // bvh.cpp:256-265
       --st.sp;
-      const uint2 e = stack_read(st, st.sp);
+      const uint2 e = stack_read<SPILL>(st, st.sp);
       if (__uint_as_float(e.y) < tmin) {
         cur = load_node(sc.nodes, e.x);
         changed = true;
@@ -409,12 +448,12 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
 // Any hit.  Q1: after a dead end the reference pops EVERYTHING and resumes at the
 // bottom-most entry; Q2: an early `return true` leaves its entries on the stack for the
 // next query of the same pixel.
-template <class CT>
+template <bool SPILL, class CT>
 __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
   float tmp;
   NodeRec cur = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
-  if (!aabb_intercepts(xyz(cur.lo), xyz(cur.hi), ray, tmp)) return false;
+  if (!aabb_intercepts(xyz(cur.lo), xyz(cur.hi), ray, tmp, false)) return false;
   while (true) {
     const uint32_t desc = __float_as_uint(cur.lo.w), index = desc_index(desc);
     bool descended = false;
@@ -422,11 +461,12 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
       float l_t, r_t;
       ct.add(kNodeTests, 2);
-      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t);
-      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t);
+      const bool fin = !__any(ray.odd_inv);  // wave-uniform: may the slab tests use max3/min3?
+      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin);
+      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin);
       if (l_hit && r_hit) {
-        if (l_t < r_t) { cur = l; push(st, index + 1, r_t, ct); }
-        else           { cur = r; push(st, index, l_t, ct); }
+        if (l_t < r_t) { cur = l; push<SPILL>(st, index + 1, r_t, ct); }
+        else           { cur = r; push<SPILL>(st, index, l_t, ct); }
         descended = true;
       } else if (l_hit) { cur = l; descended = true; }
       else if (r_hit)   { cur = r; descended = true; }
@@ -440,7 +480,7 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
     }
     if (descended) continue;
     if (st.sp > 0) {  // bvh.cpp:329-334: pop all, continue from the first-pushed entry
-      cur = load_node(sc.nodes, stack_read(st, 0).x);
+      cur = load_node(sc.nodes, stack_read<SPILL>(st, 0).x);
       st.sp = 0;
       continue;
     }
@@ -587,10 +627,10 @@ __device__ bool grid_any(const DevScene& sc, RayS& ray, CT& ct) {
 // (main.cpp:164): o + d*min_t with the caller's (mutated) ray for accel None, the
 // traversal's hit point otherwise.
 // ---------------------------------------------------------------------------
-template <int ACCEL, class CT>
+template <int ACCEL, bool SPILL, class CT>
 __device__ __forceinline__ int closest_hit(const DevScene& sc, Stack& st, RayS& ray, F3& P, Geom& g, CT& ct) {
   if (ACCEL == P3D_ACCEL_BVH) {
-    const int slot = bvh_closest(sc, st, ray, P, g, ct);
+    const int slot = bvh_closest<SPILL>(sc, st, ray, P, g, ct);
     return slot < 0 ? -1 : (int)geom_object(g);
   } else if (ACCEL == P3D_ACCEL_GRID) {
     return grid_closest(sc, ray, P, g, ct);
@@ -602,9 +642,9 @@ __device__ __forceinline__ int closest_hit(const DevScene& sc, Stack& st, RayS& 
   }
 }
 // Shadow feeler (main.cpp:196-217).  Q6: with the grid, brute force runs as well.
-template <int ACCEL, class CT>
+template <int ACCEL, bool SPILL, class CT>
 __device__ __forceinline__ bool any_hit(const DevScene& sc, Stack& st, RayS& feeler, CT& ct) {
-  if (ACCEL == P3D_ACCEL_BVH) return bvh_any(sc, st, feeler, ct);
+  if (ACCEL == P3D_ACCEL_BVH) return bvh_any<SPILL>(sc, st, feeler, ct);
   bool occluded = false;
   if (ACCEL == P3D_ACCEL_GRID) occluded = grid_any(sc, feeler, ct);
   const bool b = brute_any(sc, feeler, ct);

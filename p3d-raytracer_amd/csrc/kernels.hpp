@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
   Counters<STATS> ct;
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
-  st.base = reinterpret_cast<uint2*>(smem + P.lds_scene_f4) + lane;
+  st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
   st.spill = P.spill + (blockIdx.x * kBlock + lane);
   st.spill_stride = P.level_stride;
   st.sp = 0;
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
         while (true) {  // the reflect / refract chain of main.cpp:92-309 (a chain, not a tree: Q3)
           F3 Pn;
           Geom g;
-          const int obj = closest_hit<ACCEL>(sc, st, ray, Pn, g, ct);
+          const int obj = closest_hit<ACCEL, !LDS>(sc, st, ray, Pn, g, ct);
           if (level == 0 && si == 0 && sj == 0) first_hit = obj;
           if (obj < 0) {  // main.cpp:144-147, SKYBOX false
             result = sc.bg;
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
               RayS feeler;
               ray_set(feeler, intercept, l_dir);
               ct.add(kRaysShadow);
-              const bool shadowed = any_hit<ACCEL>(sc, st, feeler, ct);
+              const bool shadowed = any_hit<ACCEL, !LDS>(sc, st, feeler, ct);
               const F3 blinn = normalized((l_dir + get_direction(ray) * -1.0f) / 2);
               if (!shadowed) {  // main.cpp:222-225: max() and pow() evaluate in double
                 const float4 l1 = P.sc.lights[2 * li + 1];
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P) {
   extern __shared__ float4 smem[];
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   Stack st;
-  st.base = reinterpret_cast<uint2*>(smem) + threadIdx.x;
+  st.base = lds_stack_ptr(smem, 0, threadIdx.x);
   st.spill = P.spill + i;
   st.spill_stride = P.spill_stride;
   st.sp = 0;
@@ -345,11 +345,11 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P) {
   ray_set(ray, f3(P.origin[3 * i], P.origin[3 * i + 1], P.origin[3 * i + 2]),
           f3(P.direction[3 * i], P.direction[3 * i + 1], P.direction[3 * i + 2]));
   if (ANY) {
-    P.occluded[i] = any_hit<ACCEL>(P.sc, st, ray, ct) ? 1 : 0;
+    P.occluded[i] = any_hit<ACCEL, true>(P.sc, st, ray, ct) ? 1 : 0;
   } else {
     F3 hp = f3(0, 0, 0);
     Geom g;
-    const int obj = closest_hit<ACCEL>(P.sc, st, ray, hp, g, ct);
+    const int obj = closest_hit<ACCEL, true>(P.sc, st, ray, hp, g, ct);
     P.hit_id[i] = obj;
     if (obj < 0) hp = f3(0, 0, 0);
     if (P.hit_point) {

@@ -330,10 +330,13 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
 
   // main.cpp:804-812: without ANTIALIASING the frame loop always calls rayTracing
   const bool pt = cfg->integrator == P3D_PATHTRACE && cfg->antialiasing;
-  const bool lds_scene = (size_t)s->blob_f4 * sizeof(float4) <= kLdsSceneLimitBytes;
+  // worst-case node-stack height (stack_bound).  LDS-staged scenes keep the WHOLE stack in LDS
+  // (kernel variant without a spill path); deep trees / many lights use the global-memory variant,
+  // which holds the first `cap` entries in LDS and spills the rest.
   const uint32_t bound = stack_bound(s, cfg->accel, !pt);
+  const bool lds_scene = (size_t)s->blob_f4 * sizeof(float4) <= kLdsSceneLimitBytes && bound <= 24;
   const uint32_t depth_cap = std::min<uint32_t>(std::max<uint32_t>(s->bvh_max_depth + 3, 8), 24);
-  const uint32_t cap = cfg->accel == P3D_ACCEL_BVH ? std::min(bound, depth_cap) : 1;
+  const uint32_t cap = cfg->accel == P3D_ACCEL_BVH ? (lds_scene ? bound : std::min(bound, depth_cap)) : 1;
   const uint32_t spill_entries = bound > cap ? bound - cap : 0;
   const bool want_counts = stats && cfg->collect_stats;
 

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(kBlock) pt_kernel(const RenderParams P) {
   Counters<STATS> ct;
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
-  st.base = reinterpret_cast<uint2*>(smem + P.lds_scene_f4) + lane;
+  st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
   st.spill = P.spill + (blockIdx.x * kBlock + lane);
   st.spill_stride = P.level_stride;
   st.sp = 0;
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(kBlock) pt_kernel(const RenderParams P) {
       // ---- one bounce: the body of Radiance ----
       F3 Pn;
       Geom g;
-      const int obj = closest_hit<ACCEL>(sc, st, ray, Pn, g, ct);
+      const int obj = closest_hit<ACCEL, !LDS>(sc, st, ray, Pn, g, ct);
       if (first_ray) { first_hit = obj; first_ray = false; }
       if (obj < 0 || depth == 0) {  // main.cpp:350-355: the background acts as an environment light
         L = L + T * sc.bg;
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(kBlock) pt_kernel(const RenderParams P) {
           ct.add(kRaysLight);
           F3 hp2;
           Geom g2;
-          const int hit2 = closest_hit<ACCEL>(sc, st, feeler, hp2, g2, ct);
+          const int hit2 = closest_hit<ACCEL, !LDS>(sc, st, feeler, hp2, g2, ct);
           if (hit2 >= 0 && hit2 == (int)lobj) {  // main.cpp:472-475
             const double omega = (double)(2 * kPIf) * (1 - cos_a_max);
             e = e + f * (emi * dot(l, norml) * (float)omega) * (1 / kPIf);
