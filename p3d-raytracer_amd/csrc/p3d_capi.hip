@@ -301,6 +301,7 @@ int getenv_int(const char* name, int dflt) {
   return (v && *v) ? std::atoi(v) : dflt;
 }
 
+
 }  // namespace
 
 extern "C" {
