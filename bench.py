@@ -30,6 +30,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "tri100k", "cornell_pt"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (production).  gloo stages the gather through host memory: only for "
+                         "rehearsing the N>1 code path with several ranks on ONE GPU")
+    ap.add_argument("--gather", default="u8", choices=["u8", "f32"],
+                    help="N>1: what rank 0 collects per frame: the u8 image (img_Data, 3 B/px) or float RGB + hit IDs (16 B/px)")
     return ap.parse_args()
 
 
@@ -70,34 +75,54 @@ def main():
                      "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    host_staged = world > 1 and args.backend == "gloo"
 
     scene_path, cfg, base, desc = workload_setup(args.workload, world, p3d)
     stripe_h = 8
     res = int(round(base * math.sqrt(world) / (stripe_h * world))) * stripe_h * world  # multiple of stripe_h*N
     hs = p3d.HostScene(scene_path)
     hs.set_resolution(res, res)
-    dev = p3d.DeviceScene(hs, bvh=True, device=local_rank)
+    dev = p3d.DeviceScene(hs, bvh=True, device=dev_index)
     tile = p3d.stripe_tile((res, res), rank, world, stripe_h) if world > 1 else dev.full_tile()
     n_local = tile.w * tile.h
     stream = torch.cuda.current_stream()
 
-    # per-rank buffers [rgb float32 x3 | hit int32] in one allocation so that one collective moves both
-    def new_buf():
-        return torch.empty(n_local * 16, dtype=torch.uint8, device="cuda")
-    bufs = [new_buf(), new_buf()]
+    # Every rank renders ALL outputs of its stripes into HBM: float RGB + hit IDs (one packed
+    # allocation, 16 B/px) and the gamma-corrected u8 image (img_Data, 3 B/px).  Rank 0 collects
+    # one of the two per frame with a single collective (--gather).
+    def new_bufs():
+        return (torch.empty(p3d.packed_bytes(n_local), dtype=torch.uint8, device="cuda"),
+                torch.empty(n_local * 3, dtype=torch.uint8, device="cuda"))
+    bufs = [new_bufs(), new_bufs()]
     handles = [None, None]
-    gathered = [[torch.empty_like(bufs[0]) for _ in range(world)] for _ in range(2)] if (world > 1 and rank == 0) else None
-    frame_rgb = torch.empty((res, res, 3), dtype=torch.float32, device="cuda") if rank == 0 and world > 1 else None
-    frame_hit = torch.empty((res, res), dtype=torch.int32, device="cuda") if rank == 0 and world > 1 else None
+    pick = (lambda pair: pair[1]) if args.gather == "u8" else (lambda pair: pair[0])
+    gdev = "cpu" if host_staged else "cuda"
+    gathered = ([[torch.empty(pick(bufs[0]).shape, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
+                if (world > 1 and rank == 0) else None)
+    frame8 = torch.empty((res, res, 3), dtype=torch.uint8, device=gdev) if rank == 0 and world > 1 else None
+    frame_rgb = torch.empty((res, res, 3), dtype=torch.float32, device=gdev) if rank == 0 and world > 1 else None
+    frame_hit = torch.empty((res, res), dtype=torch.int32, device=gdev) if rank == 0 and world > 1 else None
 
     def assemble(slot):
-        p3d.assemble_frame(gathered[slot], (res, res), world, stripe_h, frame_rgb, frame_hit)
+        if args.gather == "u8":
+            p3d.assemble_frame8(gathered[slot], (res, res), world, stripe_h, frame8)
+        else:
+            p3d.assemble_frame(gathered[slot], (res, res), world, stripe_h, frame_rgb, frame_hit)
 
     ev_pairs = []
+
+    def render_into(pair, tile_, cfg_, stats=None):
+        packed, u8 = pair
+        dev.render_device(cfg_, tile_, d_rgb=packed.data_ptr(), d_hit=packed.data_ptr() + (tile_.w * tile_.h) * 12,
+                          d_rgb8=u8.data_ptr(), stream=stream.cuda_stream, stats=stats)
 
     def step(i, timed):
         slot = i & 1
@@ -106,16 +131,16 @@ def main():
             if rank == 0:
                 assemble(slot)
             handles[slot] = None
-        b = bufs[slot]
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-        dev.render_device(cfg, tile, d_rgb=b.data_ptr(), d_hit=b.data_ptr() + n_local * 12, stream=stream.cuda_stream)
+        render_into(bufs[slot], tile, cfg)
         if timed:
             e1.record(stream)
             ev_pairs.append((e0, e1))
         if world > 1:
-            handles[slot], _ = p3d.gather_frame(b, (res, res), rank, world, stripe_h, 0,
+            payload = pick(bufs[slot]).cpu() if host_staged else pick(bufs[slot])
+            handles[slot], _ = p3d.gather_frame(payload, (res, res), rank, world, stripe_h, 0,
                                                 gathered[slot] if rank == 0 else None, async_op=True)
 
     def drain():
@@ -143,7 +168,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
@@ -152,12 +177,27 @@ def main():
     cfg_counted = p3d.Config.from_buffer_copy(bytes(cfg))
     cfg_counted.collect_stats = 1
     st = p3d.Stats()
-    dev.render_device(cfg_counted, tile, d_rgb=bufs[0].data_ptr(), d_hit=bufs[0].data_ptr() + n_local * 12,
-                      stream=stream.cuda_stream, stats=st)
-    counts = torch.tensor([st.rays, st.algorithmic_bytes()], dtype=torch.float64, device="cuda")
+    render_into(bufs[0], tile, cfg_counted, stats=st)
+    counts = torch.tensor([st.rays, st.algorithmic_bytes()], dtype=torch.float64, device="cpu" if host_staged else "cuda")
     if world > 1:
         dist.all_reduce(counts)
     rays_total, _ = counts.tolist()
+
+    gather_check = None
+    if world > 1 and rank == 0:
+        # the last assembled frame must equal, bit for bit, what one GPU renders for the whole frame
+        full = dev.full_tile()
+        ref_pair = (torch.empty(p3d.packed_bytes(res * res), dtype=torch.uint8, device="cuda"),
+                    torch.empty(res * res * 3, dtype=torch.uint8, device="cuda"))
+        render_into(ref_pair, full, cfg)
+        torch.cuda.synchronize()
+        ref_packed, ref_u8 = ref_pair[0].to(gdev), ref_pair[1].to(gdev)
+        if args.gather == "u8":
+            ok = bool(torch.equal(frame8.view(-1), ref_u8))
+        else:
+            ok = bool(torch.equal(frame_rgb.view(-1).view(torch.int32), ref_packed[: res * res * 12].view(torch.int32))
+                      and torch.equal(frame_hit.view(-1), ref_packed[res * res * 12:].view(torch.int32)))
+        gather_check = "ok" if ok else "MISMATCH"
 
     if rank == 0:
         value = rays_total * args.steps / dt / 1e6
@@ -174,8 +214,13 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "resolution": [res, res], "rays_per_frame": int(rays_total),
                        "ray_definition": "one traversal query (closest-hit or any-hit)",
+                       "outputs_per_rank": "float RGB + hit ID (16 B/px) + u8 image (3 B/px), all written to HBM",
                        "parallelism": "image rows in %d-row stripes, round-robin over %d GPU(s)%s"
-                                      % (stripe_h, world, "; RCCL gather to rank 0" if world > 1 else "")},
+                                      % (stripe_h, world,
+                                         "; one RCCL gather per frame of the %s to rank 0, double-buffered; "
+                                         "gathered frame vs single-GPU frame: %s"
+                                         % ("u8 image" if args.gather == "u8" else "float RGB + hit IDs", gather_check)
+                                         if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                          "kernel": "whitted_kernel" if cfg.integrator == p3d.WHITTED or not cfg.antialiasing else "pt_kernel",

@@ -390,3 +390,15 @@ def gather_frame(local_buf, res, rank, world, stripe_h, dst=0, gathered=None, as
         gathered = [torch.empty_like(local_buf) for _ in range(world)]
     work = dist.gather(local_buf, gathered if rank == dst else None, dst=dst, async_op=async_op)
     return work, gathered
+
+
+def assemble_frame8(gathered, res, world, stripe_h, frame8=None):
+    """Same de-interleave for the u8 frame (img_Data, 3 B/pixel): the payload bench.py gathers by default."""
+    import torch
+    rx, ry = res
+    n_str = ry // (stripe_h * world)
+    if frame8 is None:
+        frame8 = torch.empty((ry, rx, 3), dtype=torch.uint8, device=gathered[0].device)
+    parts = [g.view(n_str, stripe_h, rx, 3) for g in gathered]
+    frame8.view(n_str, world, stripe_h, rx, 3).copy_(torch.stack(parts, dim=1))
+    return frame8

@@ -269,3 +269,24 @@ def test_cornell_path_tracer(lens):
     assert (hit == o_hit).all()
     assert np.abs(rgb - o_rgb).max() <= TOL * max(1.0, float(np.abs(o_rgb).max()))
     assert (st.rays_primary, st.rays_bounce, st.rays_light) == (o_st.rays_primary, o_st.rays_bounce, o_st.rays_light)
+
+
+def test_p3d_render_cli_writes_the_reference_image(tmp_path):
+    """The C++ front end (host/main.cpp, what the reference's main() does without the GL window):
+    load -> build BVH -> render on the GPU -> save.  The PPM must hold the oracle's u8 frame."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "p3d-raytracer_amd", "p3d_render")
+    out = str(tmp_path / "frame.ppm")
+    r = subprocess.run([exe, scene_path("balls_low.p3f"), "--whitted", "--accel", "bvh", "--depth", "3", "--aa", "0",
+                        "--res", "160", "120", "--out", out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Done:" in r.stdout and "Image file created" in r.stdout
+    raw = open(out, "rb").read()
+    header, data = raw[:15], raw[15:]
+    assert header == b"P6\n160 120\n255\n"
+    img = np.frombuffer(data, np.uint8).reshape(120, 160, 3)[::-1]   # file rows are top-down, img_Data bottom-up
+    sc = ob.Scene(scene_path("balls_low.p3f"))
+    sc.set_resolution(160, 120)
+    _, _, o8, _ = sc.render(ob.whitted_config(2, 3), want_rgb8=True)
+    assert (img == o8).all()
