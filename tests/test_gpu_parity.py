@@ -277,6 +277,7 @@ def test_p3d_render_cli_writes_the_reference_image(tmp_path):
     import subprocess
     from conftest import ROOT
     exe = os.path.join(ROOT, "p3d-raytracer_amd", "p3d_render")
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe), "p3d_render"])
     out = str(tmp_path / "frame.ppm")
     r = subprocess.run([exe, scene_path("balls_low.p3f"), "--whitted", "--accel", "bvh", "--depth", "3", "--aa", "0",
                         "--res", "160", "120", "--out", out], capture_output=True, text=True, timeout=120)
