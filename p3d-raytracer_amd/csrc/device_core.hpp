@@ -389,19 +389,43 @@ __device__ __forceinline__ NodeRec load_node(const float4* nodes, uint32_t i) {
   return n;
 }
 
+// Both traversals are written "while-while": every lane first DESCENDS through inner nodes
+// until it stands on a leaf (or has finished), then the wave processes leaves together.  The
+// per-lane sequence of node visits, tests, pushes and pops is exactly the reference's; only
+// the interleaving between lanes differs from a one-node-per-iteration loop, which would make
+// the wave execute the leaf code AND the inner-node code in almost every iteration (some lane
+// is always on a leaf).  The stack holds packed child descriptors, so a pop needs no node
+// fetch.
+
+// bvh.cpp:256-265: pop until an entry is nearer than the best hit; false = stack exhausted
+template <bool SPILL>
+__device__ __forceinline__ bool pop_closer(Stack& st, float tmin, uint32_t& desc) {
+  while (st.sp > 0) {
+    --st.sp;
+    const uint2 e = stack_read<SPILL>(st, st.sp);
+    if (__uint_as_float(e.y) < tmin) {
+      desc = e.x;
+      return true;
+    }
+  }
+  return false;
+}
+
 // Closest hit.  `ray` is the traversal's private copy (bvh.cpp:198 takes Ray by value).
 // Returns the leaf slot of the hit (-1 = miss) and the hit point d*tmin + o (bvh.cpp:271).
 template <bool SPILL, class CT>
 __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_point, Geom& hit_geom, CT& ct) {
   float tmp, tmin = FLT_MAX;
   int hit = -1;
-  NodeRec cur = load_node(sc.nodes, 0);
+  const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
-  if (!aabb_intercepts(xyz(cur.lo), xyz(cur.hi), ray, tmp, false)) return -1;  // stale entries stay (Q2)
-  while (true) {
-    const uint32_t desc = __float_as_uint(cur.lo.w), index = desc_index(desc);
-    bool descended = false;
-    if (!(desc & kDescLeaf)) {
+  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, false)) return -1;  // stale entries stay (Q2)
+  uint32_t desc = __float_as_uint(root.lo.w);
+  bool walking = true;
+  while (walking) {
+    // ---- descend: bvh.cpp:208-239 ----
+    while (walking && !(desc & kDescLeaf)) {
+      const uint32_t index = desc_index(desc);
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
       float l_t, r_t;
       ct.add(kNodeTests, 2);
@@ -410,14 +434,17 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
       const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin);
       if (is_inside(xyz(l.lo), xyz(l.hi), ray.o)) l_t = 0;  // bvh.cpp:216-217
       if (is_inside(xyz(r.lo), xyz(r.hi), ray.o)) r_t = 0;
+      const uint32_t ld = __float_as_uint(l.lo.w), rd = __float_as_uint(r.lo.w);
       if (l_hit && r_hit) {
-        if (l_t < r_t) { cur = l; push<SPILL>(st, index + 1, r_t, ct); }
-        else           { cur = r; push<SPILL>(st, index, l_t, ct); }  // ties go right (Q10)
-        descended = true;
-      } else if (l_hit) { cur = l; descended = true; }
-      else if (r_hit)   { cur = r; descended = true; }
-    } else {
-      const uint32_t n = desc_count(desc);
+        if (l_t < r_t) { desc = ld; push<SPILL>(st, rd, r_t, ct); }
+        else           { desc = rd; push<SPILL>(st, ld, l_t, ct); }  // ties go right (Q10)
+      } else if (l_hit) { desc = ld; }
+      else if (r_hit)   { desc = rd; }
+      else walking = pop_closer<SPILL>(st, tmin, desc);
+    }
+    // ---- leaf: bvh.cpp:241-252, then the pop loop ----
+    if (walking) {
+      const uint32_t index = desc_index(desc), n = desc_count(desc);
       for (uint32_t s = index; s < index + n; ++s) {
         const Geom g = load_geom(sc.bgeom, s);
         float curr_t;
@@ -427,22 +454,11 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
           hit_geom = g;
         }
       }
+      walking = pop_closer<SPILL>(st, tmin, desc);
     }
-    if (descended) continue;
-    bool changed = false;
-    while (st.sp > 0) {  // bvh.cpp:256-265
-      --st.sp;
-      const uint2 e = stack_read<SPILL>(st, st.sp);
-      if (__uint_as_float(e.y) < tmin) {
-        cur = load_node(sc.nodes, e.x);
-        changed = true;
-        break;
-      }
-    }
-    if (changed) continue;
-    if (hit >= 0) hit_point = ray.d * tmin + ray.o;
-    return hit;
   }
+  if (hit >= 0) hit_point = ray.d * tmin + ray.o;
+  return hit;
 }
 
 // Any hit.  Q1: after a dead end the reference pops EVERYTHING and resumes at the
@@ -451,41 +467,52 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
 template <bool SPILL, class CT>
 __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
   float tmp;
-  NodeRec cur = load_node(sc.nodes, 0);
+  const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
-  if (!aabb_intercepts(xyz(cur.lo), xyz(cur.hi), ray, tmp, false)) return false;
-  while (true) {
-    const uint32_t desc = __float_as_uint(cur.lo.w), index = desc_index(desc);
-    bool descended = false;
-    if (!(desc & kDescLeaf)) {
+  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, false)) return false;
+  uint32_t desc = __float_as_uint(root.lo.w);
+  bool walking = true, occluded = false;
+  // bvh.cpp:329-338: pop all, continue from the first-pushed entry; false = nothing left
+  auto restart_from_bottom = [&]() {
+    if (st.sp > 0) {
+      desc = stack_read<SPILL>(st, 0).x;
+      st.sp = 0;
+      return true;
+    }
+    return false;
+  };
+  while (walking) {
+    while (walking && !(desc & kDescLeaf)) {
+      const uint32_t index = desc_index(desc);
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
       float l_t, r_t;
       ct.add(kNodeTests, 2);
-      const bool fin = !__any(ray.odd_inv);  // wave-uniform: may the slab tests use max3/min3?
+      const bool fin = !__any(ray.odd_inv);
       const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin);
       const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin);
+      const uint32_t ld = __float_as_uint(l.lo.w), rd = __float_as_uint(r.lo.w);
       if (l_hit && r_hit) {
-        if (l_t < r_t) { cur = l; push<SPILL>(st, index + 1, r_t, ct); }
-        else           { cur = r; push<SPILL>(st, index, l_t, ct); }
-        descended = true;
-      } else if (l_hit) { cur = l; descended = true; }
-      else if (r_hit)   { cur = r; descended = true; }
-    } else {
-      const uint32_t n = desc_count(desc);
+        if (l_t < r_t) { desc = ld; push<SPILL>(st, rd, r_t, ct); }
+        else           { desc = rd; push<SPILL>(st, ld, l_t, ct); }
+      } else if (l_hit) { desc = ld; }
+      else if (r_hit)   { desc = rd; }
+      else walking = restart_from_bottom();
+    }
+    if (walking) {
+      const uint32_t index = desc_index(desc), n = desc_count(desc);
       for (uint32_t s = index; s < index + n; ++s) {
         const Geom g = load_geom(sc.bgeom, s);
         float curr_t;
-        if (intercepts(g, ray, curr_t, ct)) return true;  // entries stay behind (Q2)
+        if (intercepts(g, ray, curr_t, ct)) {  // entries stay behind (Q2)
+          occluded = true;
+          walking = false;
+          break;
+        }
       }
+      if (walking) walking = restart_from_bottom();
     }
-    if (descended) continue;
-    if (st.sp > 0) {  // bvh.cpp:329-334: pop all, continue from the first-pushed entry
-      cur = load_node(sc.nodes, stack_read<SPILL>(st, 0).x);
-      st.sp = 0;
-      continue;
-    }
-    return false;
   }
+  return occluded;
 }
 
 // ---------------------------------------------------------------------------

@@ -302,6 +302,7 @@ int getenv_int(const char* name, int dflt) {
 }
 
 
+
 }  // namespace
 
 extern "C" {
