@@ -28,7 +28,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "tri100k", "cornell_pt"])
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "tri100k", "cornell_pt"],
+                    help="cfg2 (default) = BASELINE configs[1]; cfg3/cfg4/cfg5 = configs[2]/[3]/[4] at their full sizes; "
+                         "tri100k / cornell_pt = the same scenes at quick sizes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production).  gloo stages the gather through host memory: only for "
@@ -44,7 +46,7 @@ def workload_setup(name, n_gpus, p3d):
     if name == "cfg2":
         return (os.path.join(scenes, "balls_low.p3f"), p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4), 1024,
                 "balls_low.p3f, Whitted MAX_DEPTH=4, BVH, no AA (BASELINE configs[1])")
-    if name == "tri100k":
+    if name in ("tri100k", "cfg4"):
         sys.path.insert(0, os.path.join(ROOT, "scenes"))
         import make_tri100k
         path = "/tmp/p3d_tri100k_%d.p3f" % os.getuid()
@@ -53,9 +55,19 @@ def workload_setup(name, n_gpus, p3d):
             os.replace(path + ".tmp", path)
         while not os.path.exists(path):
             time.sleep(0.2)
+        if name == "cfg4":  # BASELINE configs[3]: 2048x2048 whatever the GPU count (strong scaling)
+            return (path, p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=6), -2048,
+                    "100k random triangles 2048x2048, Whitted MAX_DEPTH=6, BVH (BASELINE configs[3])")
         return (path, p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=6), 1024,
                 "100k random triangles, Whitted MAX_DEPTH=6, BVH (BASELINE configs[3] scene)")
-    return (os.path.join(ROOT, "scenes", "cornell.p3f"), p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=4, max_depth=20),
+    cornell = os.path.join(ROOT, "scenes", "cornell.p3f")
+    if name == "cfg3":  # BASELINE configs[2]
+        return (cornell, p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=16, max_depth=20), 1024,
+                "cornell.p3f, path tracer 256 spp, MAX_DEPTH=20, BVH (BASELINE configs[2])")
+    if name == "cfg5":  # BASELINE configs[4]: thin lens (aperture 10, focal 1), 4096 spp; fixed 1024x1024
+        return (cornell, p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=64, max_depth=20, dof=1), -1024,
+                "cornell.p3f aperture 10 focal 1, path tracer 4096 spp + DOF sampler, BVH (BASELINE configs[4])")
+    return (cornell, p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=4, max_depth=20),
             512, "cornell.p3f, path tracer 16 spp, BVH (BASELINE configs[2] scene, reduced spp)")
 
 
@@ -87,9 +99,14 @@ def main():
 
     scene_path, cfg, base, desc = workload_setup(args.workload, world, p3d)
     stripe_h = 8
-    res = int(round(base * math.sqrt(world) / (stripe_h * world))) * stripe_h * world  # multiple of stripe_h*N
+    fixed = base < 0  # negative base: fixed frame size (strong scaling)
+    base = abs(base)
+    res = base if fixed else int(round(base * math.sqrt(world) / (stripe_h * world))) * stripe_h * world
+    assert res % (stripe_h * world) == 0
     hs = p3d.HostScene(scene_path)
     hs.set_resolution(res, res)
+    if args.workload == "cfg5":
+        hs.set_lens(10.0, 1.0)
     dev = p3d.DeviceScene(hs, bvh=True, device=dev_index)
     tile = p3d.stripe_tile((res, res), rank, world, stripe_h) if world > 1 else dev.full_tile()
     n_local = tile.w * tile.h
@@ -210,7 +227,8 @@ def main():
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if fixed else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "resolution": [res, res], "rays_per_frame": int(rays_total),
                        "ray_definition": "one traversal query (closest-hit or any-hit)",
@@ -242,6 +260,8 @@ def cpu_baseline(workload, scene_path, cfg, res):
     from oracle import binding as ob
     sc = ob.Scene(scene_path)
     sc.set_resolution(res, res)
+    if workload == "cfg5":
+        sc.set_lens(10.0, 1.0)
     ocfg = ob.default_config(integrator=cfg.integrator, accel=cfg.accel, max_depth=cfg.max_depth,
                              spp_sqrt=cfg.spp_sqrt, antialiasing=cfg.antialiasing,
                              depth_of_field=cfg.depth_of_field, sample_disk=cfg.sample_disk,
@@ -253,8 +273,8 @@ def cpu_baseline(workload, scene_path, cfg, res):
         reps = 5
         sample = "%d whole frames of the same workload (%dx%d), best of %d" % (reps, res, res, reps)
     else:
-        w = h = 256
-        x0 = y0 = (res - 256) // 2
+        w = h = 256 if workload in ("tri100k", "cfg4", "cornell_pt") else (64 if workload == "cfg3" else 16)
+        x0 = y0 = (res - w) // 2
         reps = 2
         sample = "centred %dx%d crop of the %dx%d frame, best of %d" % (w, h, res, res, reps)
     sc.render(ocfg, x0, y0, 8, 8)  # builds the BVH outside the timed region

@@ -291,3 +291,18 @@ def test_p3d_render_cli_writes_the_reference_image(tmp_path):
     sc.set_resolution(160, 120)
     _, _, o8, _ = sc.render(ob.whitted_config(2, 3), want_rgb8=True)
     assert (img == o8).all()
+
+
+@pytest.mark.parametrize("accel", [p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH])
+def test_planes_boxes_and_glass(accel):
+    """scenes/planes.p3f: `pl` objects (Plane::intercepts scene.cpp:116-137, default [-1,1]^3 bbox in
+    BVH/grid, Q12), an aaBox with its face normals (scene.cpp:229-267) and a refracting sphere."""
+    from conftest import ROOT
+    dev, sc = _pair(os.path.join(ROOT, "scenes", "planes.p3f"), res=(192, 192))
+    cfg = p3d.whitted_config(accel=accel, max_depth=4, collect_stats=1)
+    rgb, hit, st = dev.render(cfg)
+    o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+    compare((rgb, hit), (o_rgb, o_hit), 2e-6)
+    assert (st.plane_tests, st.box_tests, st.rays_refract, st.rays) == (o_st.plane_tests, o_st.box_tests, o_st.rays_refract, o_st.rays)
+    if accel == p3d.ACCEL_NONE:
+        assert st.plane_tests > 0 and (hit == 0).any() and (hit == 1).any()
