@@ -306,3 +306,22 @@ def test_planes_boxes_and_glass(accel):
     assert (st.plane_tests, st.box_tests, st.rays_refract, st.rays) == (o_st.plane_tests, o_st.box_tests, o_st.rays_refract, o_st.rays)
     if accel == p3d.ACCEL_NONE:
         assert st.plane_tests > 0 and (hit == 0).any() and (hit == 1).any()
+
+
+@pytest.mark.parametrize("name,spp_sqrt,lens,crop", [("cfg3", 16, None, (448, 440, 96, 96)),
+                                                     ("cfg5", 64, (10.0, 1.0), (500, 300, 24, 24))])
+def test_baseline_path_tracer_configs_at_full_sampling(name, spp_sqrt, lens, crop):
+    """BASELINE configs[2] (256 spp) and configs[4] (4096 spp, thin lens) at their real frame size
+    (1024x1024) and sample counts, on a crop the oracle can finish: per-channel tolerance 1e-4 of the
+    HDR scale, hit IDs exact, every ray/test counter identical (same paths on both sides)."""
+    from conftest import ROOT
+    dev, sc = _pair(os.path.join(ROOT, "scenes", "cornell.p3f"), res=(1024, 1024), grid=False, lens=lens)
+    cfg = p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=spp_sqrt, max_depth=20, dof=1 if lens else 0,
+                               seed=0x5EED, collect_stats=1)
+    x0, y0, w, h = crop
+    rgb, hit, st = dev.render(cfg, tile=p3d.Tile(x0, y0, w, h, 0, 1))
+    o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg, threads=16), x0, y0, w, h)
+    assert (hit == o_hit).all()
+    assert np.abs(rgb - o_rgb).max() <= TOL * max(1.0, float(np.abs(o_rgb).max()))
+    for k in ("rays_primary", "rays_bounce", "rays_light", "node_tests", "sphere_tests", "tri_tests"):
+        assert getattr(st, k) == getattr(o_st, k), k
