@@ -173,8 +173,8 @@ typedef struct p3d_scene_desc {
 } p3d_scene_desc;
 
 /* Runtime form of the compile-time options of constants.h:6-45.  p3d_config_default()
- * fills in the reference's shipped values (SKYBOX is not implemented: a miss
- * returns the background colour, i.e. SKYBOX false, main.cpp:145-146). */
+ * fills in the reference's shipped values, except SKYBOX: it defaults to 0 (miss = bclr)
+ * because the cubemap has to be supplied separately (p3d_scene_set_skybox). */
 typedef struct p3d_config {
   uint32_t integrator;    /* PATHTRACING        constants.h:36  */
   uint32_t accel;         /* acl_str            constants.h:44  */
@@ -188,6 +188,9 @@ typedef struct p3d_config {
   float light_side;       /* LIGHT_SIDE         constants.h:15  */
   float gamma;            /* GAMMA              constants.h:38  */
   uint32_t collect_stats; /* 1: fill the test/ray counters of p3d_stats (slower kernel) */
+  uint32_t skybox;        /* SKYBOX             constants.h:30: a miss returns the cubemap texel
+                             (main.cpp:145,351) instead of bclr; needs p3d_scene_set_skybox */
+  uint32_t reserved;
   uint64_t seed;          /* replaces set_rand_seed(time*time), main.cpp:722:
                              every (pixel, sample) draws from its own stream */
 } p3d_config;
@@ -239,6 +242,24 @@ void p3d_config_default(p3d_config* cfg);  /* constants.h:6-45 as shipped */
 /* Uploads the flattened scene to HBM of HIP device `device` (arrays copied). */
 int p3d_scene_create(const p3d_scene_desc* desc, int device, p3d_scene** out);
 void p3d_scene_destroy(p3d_scene* scene);
+
+/*
+ * Cubemap for miss shading = the skybox_img[6] array that Scene::LoadSkybox fills
+ * (scene.cpp:329-377, scene.h:218-223).  The caller decodes the six images (the reference
+ * uses DevIL for that; JPEG decoding is not part of this library) and hands over raw bytes:
+ * bpp 3 (RGB) or 4 (RGBA), row 0 = BOTTOM image row (IL_ORIGIN_LOWER_LEFT, scene.cpp:344-345),
+ * face order RIGHT, LEFT, TOP, BOTTOM, FRONT, BACK (enum CubeMap, scene.h:28).  The texel
+ * lookup itself (Scene::GetSkyboxColor, scene.cpp:379-457) runs in the kernels.
+ */
+typedef struct p3d_skybox_face {
+  const uint8_t* img;
+  uint32_t res_x, res_y, bpp;
+  uint32_t reserved;
+} p3d_skybox_face;
+typedef struct p3d_skybox_desc {
+  p3d_skybox_face face[6];
+} p3d_skybox_desc;
+int p3d_scene_set_skybox(p3d_scene* scene, const p3d_skybox_desc* sky);
 
 /* ---- the hot path ---- */
 /*

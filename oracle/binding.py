@@ -19,7 +19,7 @@ class OrcConfig(C.Structure):
         ("integrator", C.c_int32), ("accel", C.c_int32), ("max_depth", C.c_int32),
         ("spp_sqrt", C.c_int32), ("antialiasing", C.c_int32), ("depth_of_field", C.c_int32),
         ("sample_disk", C.c_int32), ("soft_shadows", C.c_int32), ("sample_mode", C.c_int32),
-        ("light_side", C.c_float), ("gamma", C.c_float),
+        ("light_side", C.c_float), ("gamma", C.c_float), ("skybox", C.c_int32),
         ("rng_mode", C.c_int32), ("stack_mode", C.c_int32), ("trace_zero_weight", C.c_int32),
         ("eval_order", C.c_int32), ("math_mode", C.c_int32), ("threads", C.c_int32),
         ("seed", C.c_uint64),
@@ -144,6 +144,14 @@ class Scene:
             raise RuntimeError("no camera")
         return dict(eye=eye, u=u, v=v, n=n, w=whdfa[0], h=whdfa[1], plane_dist=whdfa[2],
                     focal_ratio=whdfa[3], aperture=whdfa[4], res=res)
+
+    def set_skybox(self, faces):
+        """faces: 6 uint8 arrays (h, w, 3|4), row 0 = bottom row, order RIGHT LEFT TOP BOTTOM FRONT BACK."""
+        for i, f in enumerate(faces):
+            f = np.ascontiguousarray(f, np.uint8)
+            rc = self._L.orc_scene_set_skybox_face(self.h, i, f.ctypes.data_as(C.POINTER(C.c_uint8)), f.shape[1], f.shape[0], f.shape[2])
+            if rc != 0:
+                raise ValueError("bad skybox face %d" % i)
 
     def background(self):
         b = np.zeros(3, np.float32)

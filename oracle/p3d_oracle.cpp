@@ -498,6 +498,10 @@ struct Scene {
   float v_angle = 0, v_hither = 0, v_aperture = 0, v_focal = 0;
   C3 bg;
   bool skybox_flag = false;  // scene.cpp:610 (never read by the hot path, Q15)
+  // skybox_img[6] of scene.h:218-223: decoded bytes, row 0 = BOTTOM row (IL_ORIGIN_LOWER_LEFT,
+  // scene.cpp:344-345), order RIGHT, LEFT, TOP, BOTTOM, FRONT, BACK (scene.h:28)
+  struct Face { std::vector<uint8_t> img; unsigned resX = 0, resY = 0, BPP = 3; } sky[6];
+  bool sky_loaded = false;
   Bvh bvh;
   Grid grid;
 };
@@ -849,6 +853,42 @@ int closest_hit(Ctx& cx, Ray& ray, float& min_t, V3& hit_p) {
   return min_obj;
 }
 
+
+// Scene::GetSkyboxColor — scene.cpp:379-457.  Indexed by the RAW ray direction; the two
+// "clamp" lines scene.cpp:448,450 are expression statements without effect.
+C3 get_skybox_color(const Scene& S, const Ray& r) {
+  V3 cc = r.d;
+  float ma;
+  int side;  // RIGHT 0, LEFT 1, TOP 2, BOTTOM 3, FRONT 4, BACK 5
+  if (fabsf(cc.x) > fabsf(cc.y)) { ma = fabsf(cc.x); side = cc.x >= 0 ? 1 : 0; }
+  else                           { ma = fabsf(cc.y); side = cc.y >= 0 ? 2 : 3; }
+  if (fabsf(cc.z) > ma) { ma = fabsf(cc.z); side = cc.z >= 0 ? 4 : 5; }
+  float sc, tc;
+  switch (side) {
+    case 0: sc = -cc.z; tc = cc.y; break;
+    case 1: sc = cc.z; tc = cc.y; break;
+    case 2: sc = -cc.x; tc = -cc.z; break;
+    case 3: sc = -cc.x; tc = cc.z; break;
+    case 4: sc = -cc.x; tc = cc.y; break;
+    default: sc = cc.x; tc = cc.y; break;
+  }
+  double invMa = 1 / ma;  // int / float: a FLOAT division, widened afterwards
+  float s = (float)((sc * invMa + 1) / 2);
+  float t = (float)((tc * invMa + 1) / 2);
+  const Scene::Face& f = S.sky[side];
+  unsigned width = f.resX, height = f.resY, bpp = f.BPP;
+  unsigned xp = (unsigned)(int)((width - 1) * s);
+  unsigned yp = (unsigned)(int)((height - 1) * t);
+  if (xp >= width) xp = width - 1;   // the reference would read out of bounds here (NaN / zero direction)
+  if (yp >= height) yp = height - 1;
+  size_t idx = ((size_t)yp * width + xp) * bpp;
+  auto u8tofloat = [](uint8_t x) { return (float)(x / 255.99f); };  // maths.h:89-92
+  return c3(u8tofloat(f.img[idx]), u8tofloat(f.img[idx + 1]), u8tofloat(f.img[idx + 2]));
+}
+inline C3 miss_color(const Scene& S, const orc_config& cfg, const Ray& r) {  // main.cpp:144-147 / 350-355
+  return (cfg.skybox && S.sky_loaded) ? get_skybox_color(S, r) : S.bg;
+}
+
 inline V3 offset_intersection(V3 inter, V3 normal) { return inter + normal * .0001f; }  // main.cpp:82-84
 
 // ---------------------------------------------------------------------------
@@ -862,7 +902,7 @@ C3 ray_tracing(Ctx& cx, Ray ray, int depth, float ior_1, int off_x, int off_y, b
   float min_t;
   int min_obj = closest_hit(cx, ray, min_t, hit_p);
   if (primary_hit) *primary_hit = min_obj;
-  if (min_obj < 0) return S.bg;  // main.cpp:144-147 with SKYBOX false
+  if (min_obj < 0) return miss_color(S, cfg, ray);  // main.cpp:144-147
 
   const Object& ob = S.objects[min_obj];
   const Material& mat = S.materials[ob.mat];
@@ -987,7 +1027,7 @@ C3 radiance(Ctx& cx, Ray ray, int depth, float ior_1, int off_x, int off_y, bool
   float min_t;
   int min_obj = closest_hit(cx, ray, min_t, hit_p);
   if (primary_hit) *primary_hit = min_obj;
-  if (min_obj < 0 || depth == 0) return S.bg;  // main.cpp:350-355
+  if (min_obj < 0 || depth == 0) return miss_color(S, cfg, ray);  // main.cpp:350-355
 
   const Object& ob = S.objects[min_obj];
   const Material& mat = S.materials[ob.mat];
@@ -1330,7 +1370,7 @@ void orc_config_default(orc_config* c) {  // constants.h:6-45 as shipped (SKYBOX
   memset(c, 0, sizeof(*c));
   c->integrator = 1; c->accel = 2; c->max_depth = 20; c->spp_sqrt = 20; c->antialiasing = 1;
   c->depth_of_field = 1; c->sample_disk = 1; c->soft_shadows = 0; c->sample_mode = 0;
-  c->light_side = .5f; c->gamma = 1.0f;
+  c->light_side = .5f; c->gamma = 1.0f; c->skybox = 0;
   c->rng_mode = 0; c->stack_mode = 0; c->trace_zero_weight = 0; c->eval_order = 0; c->threads = 1;
   c->seed = 0x5EED;
 }
@@ -1439,6 +1479,15 @@ int orc_scene_camera(void* s, float* eye3, float* u3, float* v3_, float* n3, flo
   n3[0] = c.n.x; n3[1] = c.n.y; n3[2] = c.n.z;
   whdfa5[0] = c.w; whdfa5[1] = c.h; whdfa5[2] = c.plane_dist; whdfa5[3] = c.focal_ratio; whdfa5[4] = c.aperture;
   res2[0] = c.res_x; res2[1] = c.res_y;
+  return 0;
+}
+int orc_scene_set_skybox_face(void* s, int face, const uint8_t* img, unsigned res_x, unsigned res_y, unsigned bpp) {
+  Scene* S = (Scene*)s;
+  if (face < 0 || face > 5 || !img || res_x == 0 || res_y == 0 || (bpp != 3 && bpp != 4)) return -1;
+  S->sky[face].img.assign(img, img + (size_t)res_x * res_y * bpp);
+  S->sky[face].resX = res_x; S->sky[face].resY = res_y; S->sky[face].BPP = bpp;
+  S->sky_loaded = true;
+  for (int i = 0; i < 6; i++) if (S->sky[i].img.empty()) S->sky_loaded = false;
   return 0;
 }
 int orc_scene_background(void* s, float* rgb3) {

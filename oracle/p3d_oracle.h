@@ -24,6 +24,7 @@ typedef struct orc_config {
   int32_t sample_mode;  /* 0 jitter, 1 tent */
   float light_side;
   float gamma;
+  int32_t skybox;       /* SKYBOX constants.h:30: miss colour = cubemap texel (needs orc_scene_set_skybox_face x6) */
   /* --- semantics switches (see DESIGN.md "Sequential state") --- */
   int32_t rng_mode;      /* 0: one PCG32 stream per (pixel, sample) keyed by `seed`
                             1: libc rand() in program order, srand((unsigned)seed) once per
@@ -73,6 +74,9 @@ int orc_scene_light(void* s, int i, float* pos3, float* col3);
 int orc_scene_camera(void* s, float* eye3, float* u3, float* v3, float* n3, float* whdfa5,
                      int* res2);
 int orc_scene_background(void* s, float* rgb3);
+/* decoded face bytes (what Scene::LoadSkybox stores, scene.cpp:329-377): row 0 = bottom row,
+ * face order RIGHT, LEFT, TOP, BOTTOM, FRONT, BACK (scene.h:28) */
+int orc_scene_set_skybox_face(void* s, int face, const uint8_t* img, unsigned res_x, unsigned res_y, unsigned bpp);
 
 /* bvh.cpp:89-196 / grid.cpp:3-68; idempotent */
 int orc_build_bvh(void* s);

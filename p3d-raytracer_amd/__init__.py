@@ -27,7 +27,7 @@ LOAD_LEGACY_F11 = 1
 
 EXPORTS = [
     "p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_config_default",
-    "p3d_scene_create", "p3d_scene_destroy", "p3d_render_tile", "p3d_render_tile_device",
+    "p3d_scene_create", "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_render_tile", "p3d_render_tile_device",
     "p3d_trace_closest", "p3d_trace_any", "p3d_host_scene_load", "p3d_host_scene_destroy",
     "p3d_host_scene_set_resolution", "p3d_host_scene_set_lens", "p3d_host_scene_replicate_lights",
     "p3d_host_scene_desc",
@@ -89,7 +89,16 @@ class Config(C.Structure):
                 ("spp_sqrt", C.c_uint32), ("antialiasing", C.c_uint32), ("depth_of_field", C.c_uint32),
                 ("sample_disk", C.c_uint32), ("soft_shadows", C.c_uint32), ("sample_mode", C.c_uint32),
                 ("light_side", C.c_float), ("gamma", C.c_float), ("collect_stats", C.c_uint32),
-                ("seed", C.c_uint64)]
+                ("skybox", C.c_uint32), ("reserved", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class SkyboxFace(C.Structure):
+    _fields_ = [("img", C.c_void_p), ("res_x", C.c_uint32), ("res_y", C.c_uint32), ("bpp", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class SkyboxDesc(C.Structure):
+    _fields_ = [("face", SkyboxFace * 6)]
 
 
 class Tile(C.Structure):
@@ -151,6 +160,7 @@ def lib():
         L.p3d_host_scene_desc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(SceneDesc))]
         L.p3d_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.p3d_scene_destroy.argtypes = [C.c_void_p]
+        L.p3d_scene_set_skybox.argtypes = [C.c_void_p, C.POINTER(SkyboxDesc)]
         L.p3d_render_tile.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(Tile), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.POINTER(Stats)]
         L.p3d_render_tile_device.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(Tile), C.c_void_p,
@@ -299,6 +309,16 @@ class DeviceScene:
         except Exception:
             pass
 
+    def set_skybox(self, faces):
+        """faces: 6 uint8 arrays (h, w, 3|4), row 0 = BOTTOM row, order RIGHT LEFT TOP BOTTOM FRONT BACK
+        (what Scene::LoadSkybox keeps, scene.cpp:329-377).  See load_skybox_dir for JPEG folders."""
+        keep = [np.ascontiguousarray(f, np.uint8) for f in faces]
+        d = SkyboxDesc()
+        for i, f in enumerate(keep):
+            d.face[i].img = f.ctypes.data
+            d.face[i].res_x, d.face[i].res_y, d.face[i].bpp = f.shape[1], f.shape[0], f.shape[2]
+        _check(self._L.p3d_scene_set_skybox(self._h, C.byref(d)))
+
     def full_tile(self):
         return Tile(0, 0, self.res[0], self.res[1], 0, 1)
 
@@ -402,3 +422,18 @@ def assemble_frame8(gathered, res, world, stripe_h, frame8=None):
     parts = [g.view(n_str, stripe_h, rx, 3) for g in gathered]
     frame8.view(n_str, world, stripe_h, rx, 3).copy_(torch.stack(parts, dim=1))
     return frame8
+
+
+SKYBOX_FACE_FILES = ("right", "left", "top", "bottom", "front", "back")  # scene.cpp:333
+
+
+def load_skybox_dir(sky_dir, ext=".jpg"):
+    """Decode <dir>/{right,left,top,bottom,front,back}.jpg the way Scene::LoadSkybox asks DevIL to
+    (RGB bytes, lower-left origin).  Decoding is host-binding work (PIL here, DevIL in the reference);
+    the texel values are whatever the decoder produces."""
+    from PIL import Image
+    faces = []
+    for name in SKYBOX_FACE_FILES:
+        img = Image.open(os.path.join(sky_dir, name + ext)).convert("RGB")
+        faces.append(np.ascontiguousarray(np.asarray(img)[::-1]))
+    return faces

@@ -212,6 +212,9 @@ struct DevScene {
   DevCamera cam;
   F3 bg;
   DevGrid grid;
+  // cubemap faces as RGBA8 words, row 0 = bottom row; null when no skybox was supplied
+  const uint32_t* sky[6];
+  uint32_t sky_w[6], sky_h[6];
 };
 
 // Per-lane traversal stack (bvh.cpp:86 hit_stack, one per pixel instead of one per process:
@@ -676,6 +679,41 @@ __device__ __forceinline__ bool any_hit(const DevScene& sc, Stack& st, RayS& fee
   if (ACCEL == P3D_ACCEL_GRID) occluded = grid_any(sc, feeler, ct);
   const bool b = brute_any(sc, feeler, ct);
   return occluded || b;
+}
+
+// Scene::GetSkyboxColor — scene.cpp:379-457, indexed by the RAW ray direction.  The reference's
+// two clamp lines (scene.cpp:448,450) are expression statements without effect; here the index
+// IS clamped so that a NaN / zero direction cannot read out of bounds.
+__device__ inline F3 skybox_color(const DevScene& sc, F3 d) {
+  float ma;
+  int side;  // RIGHT 0, LEFT 1, TOP 2, BOTTOM 3, FRONT 4, BACK 5
+  if (fabsf(d.x) > fabsf(d.y)) { ma = fabsf(d.x); side = d.x >= 0 ? 1 : 0; }
+  else                         { ma = fabsf(d.y); side = d.y >= 0 ? 2 : 3; }
+  if (fabsf(d.z) > ma) { ma = fabsf(d.z); side = d.z >= 0 ? 4 : 5; }
+  float s_c, t_c;
+  switch (side) {
+    case 0: s_c = -d.z; t_c = d.y; break;
+    case 1: s_c = d.z; t_c = d.y; break;
+    case 2: s_c = -d.x; t_c = -d.z; break;
+    case 3: s_c = -d.x; t_c = d.z; break;
+    case 4: s_c = -d.x; t_c = d.y; break;
+    default: s_c = d.x; t_c = d.y; break;
+  }
+  const double invMa = (double)(1 / ma);  // `1 / ma` is a float division widened afterwards
+  const float s = (float)((s_c * invMa + 1) / 2);
+  const float t = (float)((t_c * invMa + 1) / 2);
+  const uint32_t width = sc.sky_w[side], height = sc.sky_h[side];
+  uint32_t xp = (uint32_t)(int)((float)(width - 1) * s);
+  uint32_t yp = (uint32_t)(int)((float)(height - 1) * t);
+  xp = xp >= width ? width - 1 : xp;
+  yp = yp >= height ? height - 1 : yp;
+  const uint32_t px = sc.sky[side][(size_t)yp * width + xp];
+  // u8tofloat, maths.h:89-92
+  return f3((float)(px & 0xffu) / 255.99f, (float)((px >> 8) & 0xffu) / 255.99f, (float)((px >> 16) & 0xffu) / 255.99f);
+}
+// miss colour of main.cpp:144-147 / 350-355
+__device__ __forceinline__ F3 miss_color(const DevScene& sc, bool skybox, F3 raw_direction) {
+  return skybox ? skybox_color(sc, raw_direction) : sc.bg;
 }
 
 __device__ __forceinline__ F3 offset_intersection(F3 inter, F3 normal) { return inter + normal * .0001f; }  // main.cpp:82-84

@@ -31,6 +31,7 @@ struct RenderParams {
   int32_t max_depth;
   uint32_t spp_sqrt, antialiasing, depth_of_field, sample_disk, soft_shadows, sample_mode;
   float light_side, gamma;
+  uint32_t skybox;  // miss = cubemap texel (only set when the scene has a cubemap)
   uint64_t seed;
   // tile
   int32_t x0, y0, w, h, stripe_h, stripe_stride;
@@ -193,8 +194,8 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
           Geom g;
           const int obj = closest_hit<ACCEL, !LDS>(sc, st, ray, Pn, g, ct);
           if (level == 0 && si == 0 && sj == 0) first_hit = obj;
-          if (obj < 0) {  // main.cpp:144-147, SKYBOX false
-            result = sc.bg;
+          if (obj < 0) {  // main.cpp:144-147
+            result = miss_color(sc, P.skybox != 0, ray.d);
             break;
           }
           ct.add(kShadedHits);

@@ -60,6 +60,8 @@ struct p3d_scene {
   uint32_t* d_cell_start = nullptr;
   uint32_t* d_cell_items = nullptr;
   uint32_t* d_emitters = nullptr;
+  uint32_t* d_sky[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool has_sky = false;
   DevScene dev{};
   bool has_bvh = false, has_grid = false;
   uint32_t bvh_max_depth = 0;
@@ -85,6 +87,7 @@ void p3d_scene_destroy(p3d_scene* s) {
   if (s->d_cell_items) (void)hipFree(s->d_cell_items);
   if (s->d_emitters) (void)hipFree(s->d_emitters);
   if (s->d_stats) (void)hipFree(s->d_stats);
+  for (uint32_t*& f : s->d_sky) if (f) (void)hipFree(f);
   s->levels.release(); s->spill.release(); s->out_rgb.release(); s->out_hit.release();
   s->out_rgb8.release(); s->q_in.release(); s->q_out.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -241,6 +244,31 @@ int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
 
 }  // extern "C"
 
+extern "C" int p3d_scene_set_skybox(p3d_scene* s, const p3d_skybox_desc* sky) {
+  if (!s || !sky) return fail(P3D_ERR_INVALID, "p3d_scene_set_skybox: null argument");
+  for (int f = 0; f < 6; ++f) {
+    const p3d_skybox_face& a = sky->face[f];
+    if (!a.img || a.res_x == 0 || a.res_y == 0 || (a.bpp != 3 && a.bpp != 4) || (uint64_t)a.res_x * a.res_y > (1ull << 28))
+      return fail(P3D_ERR_INVALID, "p3d_scene_set_skybox: bad face (need img, res > 0, bpp 3 or 4)");
+  }
+  P3D_HIP(hipSetDevice(s->device));
+  for (int f = 0; f < 6; ++f) {
+    const p3d_skybox_face& a = sky->face[f];
+    const size_t n = (size_t)a.res_x * a.res_y;
+    std::vector<uint32_t> rgba(n);  // one 4-byte texel fetch instead of three byte loads
+    for (size_t i = 0; i < n; ++i)
+      rgba[i] = (uint32_t)a.img[i * a.bpp] | ((uint32_t)a.img[i * a.bpp + 1] << 8) | ((uint32_t)a.img[i * a.bpp + 2] << 16);
+    if (s->d_sky[f]) { (void)hipFree(s->d_sky[f]); s->d_sky[f] = nullptr; }
+    P3D_HIP(hipMalloc((void**)&s->d_sky[f], n * 4));
+    P3D_HIP(hipMemcpy(s->d_sky[f], rgba.data(), n * 4, hipMemcpyHostToDevice));
+    s->dev.sky[f] = s->d_sky[f];
+    s->dev.sky_w[f] = a.res_x;
+    s->dev.sky_h[f] = a.res_y;
+  }
+  s->has_sky = true;
+  return P3D_OK;
+}
+
 // ---------------------------------------------------------------------------
 // dispatch
 // ---------------------------------------------------------------------------
@@ -327,6 +355,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   if (cfg->soft_shadows && !cfg->antialiasing)
     ;  // light replication (main.cpp:725-745) is a host-side scene edit: p3d_host_scene_replicate_lights
   if (cfg->accel == P3D_ACCEL_GRID && s->dev.n_objs == 0) return fail(P3D_ERR_UNSUPPORTED, "grid over an empty scene");
+  if (cfg->skybox && !s->has_sky) return fail(P3D_ERR_INVALID, "config asks for SKYBOX but no cubemap was supplied (p3d_scene_set_skybox)");
   P3D_HIP(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)hip_stream;
 
@@ -350,6 +379,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   P.max_depth = cfg->max_depth; P.spp_sqrt = cfg->spp_sqrt; P.antialiasing = cfg->antialiasing;
   P.depth_of_field = cfg->depth_of_field; P.sample_disk = cfg->sample_disk; P.soft_shadows = cfg->soft_shadows;
   P.sample_mode = cfg->sample_mode; P.light_side = cfg->light_side; P.gamma = cfg->gamma; P.seed = cfg->seed;
+  P.skybox = cfg->skybox ? 1u : 0u;
   P.stripe_h = tile->stripe_h > 0 ? tile->stripe_h : 0; P.stripe_stride = ss;
   P.stats = s->d_stats;
   P.stack_cap = (int32_t)cap;

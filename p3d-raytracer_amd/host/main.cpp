@@ -6,6 +6,8 @@
 //   p3d_render [scene.p3f] [--whitted|--pathtrace] [--accel none|grid|bvh] [--depth N]
 //              [--spp N(sqrt)] [--aa 0|1] [--dof 0|1] [--soft 0|1] [--tent] [--gamma G]
 //              [--res W H] [--seed S] [--legacy-f11] [--out image.ppm] [--device D]
+//              [--skybox DIR]   DIR/{right,left,top,bottom,front,back}.ppm (binary P6; convert the
+//                               reference's JPEGs once with scenes/skybox_to_ppm.py) -> SKYBOX true
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -34,12 +36,30 @@ bool save_ppm(const std::string& path, const std::vector<uint8_t>& rgb8, int w, 
   return (bool)f;
 }
 
+// One cubemap face from a binary PPM, stored bottom row first like DevIL's lower-left origin
+// (scene.cpp:344-345).  JPEG decoding is deliberately not part of this program.
+bool load_ppm_face(const std::string& path, std::vector<uint8_t>& bytes, uint32_t& w, uint32_t& h) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::string magic;
+  int maxv = 0;
+  f >> magic >> w >> h >> maxv;
+  if (magic != "P6" || maxv != 255 || w == 0 || h == 0) return false;
+  f.get();
+  std::vector<uint8_t> top_down((size_t)w * h * 3);
+  f.read(reinterpret_cast<char*>(top_down.data()), (std::streamsize)top_down.size());
+  if (!f) return false;
+  bytes.resize(top_down.size());
+  for (uint32_t y = 0; y < h; ++y) std::memcpy(&bytes[(size_t)y * w * 3], &top_down[(size_t)(h - 1 - y) * w * 3], (size_t)w * 3);
+  return true;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
   p3d_config cfg;
   p3d_config_default(&cfg);
-  std::string scene_path, out = "RT_Output.ppm";  // main.cpp:851 writes RT_Output.png
+  std::string scene_path, skybox_dir, out = "RT_Output.ppm";  // main.cpp:851 writes RT_Output.png
   int res_w = 0, res_h = 0, device = 0;
   uint32_t load_flags = 0;
   for (int i = 1; i < argc; ++i) {
@@ -64,6 +84,7 @@ int main(int argc, char** argv) {
     else if (a == "--res") { res_w = std::atoi(next("--res")); res_h = std::atoi(next("--res")); }
     else if (a == "--legacy-f11") load_flags |= P3D_LOAD_LEGACY_F11;
     else if (a == "--out") out = next("--out");
+    else if (a == "--skybox") skybox_dir = next("--skybox");
     else if (a == "--device") device = std::atoi(next("--device"));
     else if (a[0] != '-') scene_path = a;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
@@ -92,6 +113,22 @@ int main(int argc, char** argv) {
   std::printf("\nResolutionX = %d  ResolutionY= %d.\n", W, H);  // main.cpp:986
   p3d_scene* scene = nullptr;
   if (p3d_scene_create(desc, device, &scene) != P3D_OK) return die("scene_create");
+  if (!skybox_dir.empty()) {  // Scene::LoadSkybox (scene.cpp:329-377) + SKYBOX true (constants.h:30)
+    static const char* names[6] = {"right", "left", "top", "bottom", "front", "back"};
+    std::vector<uint8_t> bytes[6];
+    p3d_skybox_desc sky{};
+    for (int i = 0; i < 6; ++i) {
+      uint32_t w = 0, h = 0;
+      if (!load_ppm_face(skybox_dir + "/" + names[i] + ".ppm", bytes[i], w, h)) {
+        std::fprintf(stderr, "cannot read %s/%s.ppm\n", skybox_dir.c_str(), names[i]);
+        return 1;
+      }
+      std::printf("Skybox face %d: Image sucessfully loaded.\n", i);  // scene.cpp:352
+      sky.face[i].img = bytes[i].data(); sky.face[i].res_x = w; sky.face[i].res_y = h; sky.face[i].bpp = 3;
+    }
+    if (p3d_scene_set_skybox(scene, &sky) != P3D_OK) return die("skybox");
+    cfg.skybox = 1;
+  }
   const auto t_build1 = std::chrono::high_resolution_clock::now();
 
   std::vector<uint8_t> img((size_t)3 * W * H);

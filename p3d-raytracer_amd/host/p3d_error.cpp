@@ -33,6 +33,7 @@ void p3d_config_default(p3d_config* c) {
   c->light_side = .5f;             // LIGHT_SIDE
   c->gamma = 1.0f;                 // GAMMA
   c->collect_stats = 0;
+  c->skybox = 0;                   // SKYBOX is true as shipped, but the cubemap must be supplied first
   c->seed = 0x5EED;
 }
 }

@@ -25,7 +25,7 @@ def oracle_cfg_like(cfg, **kw):
     base = dict(integrator=cfg.integrator, accel=cfg.accel, max_depth=cfg.max_depth, spp_sqrt=cfg.spp_sqrt,
                 antialiasing=cfg.antialiasing, depth_of_field=cfg.depth_of_field, sample_disk=cfg.sample_disk,
                 soft_shadows=cfg.soft_shadows, sample_mode=cfg.sample_mode, light_side=cfg.light_side,
-                gamma=cfg.gamma, seed=cfg.seed, rng_mode=0, stack_mode=0, trace_zero_weight=0, math_mode=0,
+                gamma=cfg.gamma, skybox=cfg.skybox, seed=cfg.seed, rng_mode=0, stack_mode=0, trace_zero_weight=0, math_mode=0,
                 threads=8)
     base.update(kw)
     return ob.default_config(**base)
@@ -325,3 +325,52 @@ def test_baseline_path_tracer_configs_at_full_sampling(name, spp_sqrt, lens, cro
     assert np.abs(rgb - o_rgb).max() <= TOL * max(1.0, float(np.abs(o_rgb).max()))
     for k in ("rays_primary", "rays_bounce", "rays_light", "node_tests", "sphere_tests", "tri_tests"):
         assert getattr(st, k) == getattr(o_st, k), k
+
+
+def _synthetic_skybox(seed=11):
+    """Six faces of different sizes, one of them RGBA: smooth gradients + noise so that a wrong face,
+    a flipped axis or an off-by-one texel shows up."""
+    rng = np.random.default_rng(seed)
+    faces = []
+    for i, (w, h, bpp) in enumerate([(64, 64, 3), (96, 48, 3), (33, 57, 4), (64, 64, 3), (128, 16, 3), (17, 17, 3)]):
+        yy, xx = np.mgrid[0:h, 0:w]
+        f = np.zeros((h, w, bpp), np.uint8)
+        f[..., 0] = (xx * 255 // max(w - 1, 1)).astype(np.uint8)
+        f[..., 1] = (yy * 255 // max(h - 1, 1)).astype(np.uint8)
+        f[..., 2] = (40 * i + rng.integers(0, 30, (h, w))).astype(np.uint8)
+        faces.append(f)
+    return faces
+
+
+@pytest.mark.parametrize("scene,integrator", [("balls_low.p3f", p3d.WHITTED), ("path_balls.p3f", p3d.PATHTRACE),
+                                              ("balls_medium.p3f", p3d.WHITTED)])
+@pytest.mark.parametrize("accel", [p3d.ACCEL_NONE, p3d.ACCEL_BVH])
+def test_skybox_miss_shading(scene, integrator, accel):
+    """SKYBOX true (constants.h:30): Scene::GetSkyboxColor (scene.cpp:379-457) on every miss, primary
+    and secondary (reflections of the sky in the spheres, environment light in the path tracer).
+    balls_medium = empty scene: the whole frame is the cubemap."""
+    dev, sc = _pair(scene_path(scene), res=(128, 128), grid=False)
+    faces = _synthetic_skybox()
+    dev.set_skybox(faces)
+    sc.set_skybox(faces)
+    if integrator == p3d.WHITTED:
+        cfg = p3d.whitted_config(accel=accel, max_depth=3, skybox=1)
+        tol = 2e-6
+    else:
+        cfg = p3d.pathtrace_config(accel=accel, spp_sqrt=3, max_depth=20, skybox=1)
+        tol = TOL
+    rgb, hit, _ = dev.render(cfg)
+    o_rgb, o_hit, _ = sc.render(oracle_cfg_like(cfg, skybox=1))
+    assert (hit == o_hit).all()
+    assert np.abs(rgb - o_rgb).max() <= tol * max(1.0, float(np.abs(o_rgb).max()))
+    if scene == "balls_medium.p3f":
+        assert (hit == -1).all() and len(np.unique(rgb.reshape(-1, 3), axis=0)) > 500
+    # and the switch is really a switch
+    plain, _, _ = dev.render(p3d.whitted_config(accel=accel, max_depth=3, skybox=0))
+    assert np.abs(plain - rgb).max() > 0.05
+
+
+def test_skybox_requested_without_cubemap_is_an_error():
+    dev, _ = _pair(scene_path("balls_low.p3f"), res=(32, 32), grid=False)
+    with pytest.raises(p3d.P3DError):
+        dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=1, skybox=1))

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     assert C.sizeof(p3d.Prim) == 96 and C.sizeof(p3d.Material) == 64 and C.sizeof(p3d.Light) == 32
     assert C.sizeof(p3d.Camera) == 80 and C.sizeof(p3d.BvhNode) == 32
-    assert C.sizeof(p3d.Config) == 56 and C.sizeof(p3d.Tile) == 24 and C.sizeof(p3d.Stats) == 15 * 8
+    assert C.sizeof(p3d.Config) == 64 and C.sizeof(p3d.Tile) == 24 and C.sizeof(p3d.Stats) == 15 * 8
 
 
 def test_config_default_is_constants_h():

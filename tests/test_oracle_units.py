@@ -99,3 +99,37 @@ def test_sphere_test_mutates_the_ray_direction():
     assert hit and abs(np.linalg.norm(d) - 1) < 1e-6 and abs(t - (np.sqrt(2.1 ** 2 + 1.3 ** 2 + 1.7 ** 2) - 0.5)) < 1e-5
     hit, t, d2 = sc.object_intercepts(0, [2.1, 1.3, 1.7], [-4.2, -2.6, -3.4])  # triangle: direction untouched
     assert (d2 == np.array([-4.2, -2.6, -3.4], np.float32)).all()
+
+
+def test_skybox_lookup_against_a_numpy_restatement():
+    """Scene::GetSkyboxColor (scene.cpp:379-457) re-derived independently in numpy on the primary rays
+    of an empty scene: face choice (+x -> LEFT, -x -> RIGHT, +y -> TOP, -y -> BOTTOM, +z -> FRONT,
+    -z -> BACK; |x| > |y| strict, |z| > max strict), the (s,t) axes per face, nearest texel by
+    truncation, u8 / 255.99."""
+    sc = ob.Scene(scene_path("balls_medium.p3f"))   # 0 objects with the shipped parser
+    sc.set_resolution(96, 96)
+    rng = np.random.default_rng(4)
+    faces = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (w, h) in ((32, 32), (48, 24), (20, 40), (32, 32), (64, 8), (9, 9))]
+    sc.set_skybox(faces)
+    rgb, hit, _ = sc.render(ob.whitted_config(0, 0, skybox=1))
+    assert (hit == -1).all()
+    exp = np.zeros_like(rgb)
+    for y in range(96):
+        for x in range(96):
+            _, d = sc.primary_ray(x + 0.5, y + 0.5)
+            ax, ay, az = abs(d[0]), abs(d[1]), abs(d[2])
+            if ax > ay:
+                ma, side = ax, (1 if d[0] >= 0 else 0)
+            else:
+                ma, side = ay, (2 if d[1] >= 0 else 3)
+            if az > ma:
+                ma, side = az, (4 if d[2] >= 0 else 5)
+            s_c, t_c = [(-d[2], d[1]), (d[2], d[1]), (-d[0], -d[2]), (-d[0], d[2]), (-d[0], d[1]), (d[0], d[1])][side]
+            inv = float(np.float32(1.0) / np.float32(ma))
+            s = np.float32((float(s_c) * inv + 1) / 2)
+            t = np.float32((float(t_c) * inv + 1) / 2)
+            f = faces[side]
+            xp = int(np.float32(f.shape[1] - 1) * s)
+            yp = int(np.float32(f.shape[0] - 1) * t)
+            exp[y, x] = (f[yp, xp].astype(np.float32) / np.float32(255.99)).astype(np.float32)
+    assert (rgb.view(np.uint32) == exp.view(np.uint32)).all()
