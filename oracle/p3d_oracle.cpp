@@ -110,6 +110,15 @@ const float kEPS = 0.0001f;                  // scene.h:31
 // maths.h:31-49 — double min/max/clamp
 inline double dmax(double a, double b) { return a > b ? a : b; }
 inline double dclamp(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// Cell index as grid.cpp:37-55 / 343-351 compute it: (int)clamp(v, 0, n-1).  clamp() passes a NaN
+// through (axis-parallel ray lying in a slab plane: 0 * inf) and the reference then indexes
+// cells.at(INT_MIN...) and dies with std::out_of_range.  There is no behaviour to reproduce, so the
+// oracle and the kernels both map a NaN to cell 0 (what v_cvt_i32_f32 gives) and go on.
+inline int cell_coord(double v, int n) {
+  const double c = dclamp(v, 0, n - 1);
+  if (!(c >= 0)) return 0;
+  return (int)c;
+}
 
 // ---------------------------------------------------------------------------
 // detmath: sin/cos built only from IEEE double + - * and floor, so that this
@@ -607,12 +616,12 @@ void Grid::build(const Scene& s) {  // grid.cpp:3-68, bounds grid.cpp:211-259
   cells.resize(cell_num);
   for (int j = 0; j < num_obj; j++) {
     Box ob = bounding_box(s.objects[j]);
-    int ixmin = (int)dclamp((ob.mn.x - p0.x) * nx / (p1.x - p0.x), 0, nx - 1);
-    int iymin = (int)dclamp((ob.mn.y - p0.y) * ny / (p1.y - p0.y), 0, ny - 1);
-    int izmin = (int)dclamp((ob.mn.z - p0.z) * nz / (p1.z - p0.z), 0, nz - 1);
-    int ixmax = (int)dclamp((ob.mx.x - p0.x) * nx / (p1.x - p0.x), 0, nx - 1);
-    int iymax = (int)dclamp((ob.mx.y - p0.y) * ny / (p1.y - p0.y), 0, ny - 1);
-    int izmax = (int)dclamp((ob.mx.z - p0.z) * nz / (p1.z - p0.z), 0, nz - 1);
+    int ixmin = cell_coord((ob.mn.x - p0.x) * nx / (p1.x - p0.x), nx);
+    int iymin = cell_coord((ob.mn.y - p0.y) * ny / (p1.y - p0.y), ny);
+    int izmin = cell_coord((ob.mn.z - p0.z) * nz / (p1.z - p0.z), nz);
+    int ixmax = cell_coord((ob.mx.x - p0.x) * nx / (p1.x - p0.x), nx);
+    int iymax = cell_coord((ob.mx.y - p0.y) * ny / (p1.y - p0.y), ny);
+    int izmax = cell_coord((ob.mx.z - p0.z) * nz / (p1.z - p0.z), nz);
     for (int iz = izmin; iz <= izmax; iz++)
       for (int iy = iymin; iy <= iymax; iy++)
         for (int ix = ixmin; ix <= ixmax; ix++) cells.at(ix + nx * iy + nx * ny * iz).push_back(j);
@@ -750,14 +759,14 @@ bool grid_init_traverse(const Grid& G, Ray& ray, GridWalk& k) {
   k.dty = (ty_max - ty_min) / ny;
   k.dtz = (tz_max - tz_min) / nz;
   if (is_inside(G.bbox, o)) {
-    k.ix = (int)dclamp((o.x - bmn.x) * nx / (bmx.x - bmn.x), 0, nx - 1);
-    k.iy = (int)dclamp((o.y - bmn.y) * ny / (bmx.y - bmn.y), 0, ny - 1);
-    k.iz = (int)dclamp((o.z - bmn.z) * nz / (bmx.z - bmn.z), 0, nz - 1);
+    k.ix = cell_coord((o.x - bmn.x) * nx / (bmx.x - bmn.x), nx);
+    k.iy = cell_coord((o.y - bmn.y) * ny / (bmx.y - bmn.y), ny);
+    k.iz = cell_coord((o.z - bmn.z) * nz / (bmx.z - bmn.z), nz);
   } else {
     V3 p = o + dir * t0;
-    k.ix = (int)dclamp((p.x - bmn.x) * nx / (bmx.x - bmn.x), 0, nx - 1);
-    k.iy = (int)dclamp((p.y - bmn.y) * ny / (bmx.y - bmn.y), 0, ny - 1);
-    k.iz = (int)dclamp((p.z - bmn.z) * nz / (bmx.z - bmn.z), 0, nz - 1);
+    k.ix = cell_coord((p.x - bmn.x) * nx / (bmx.x - bmn.x), nx);
+    k.iy = cell_coord((p.y - bmn.y) * ny / (bmx.y - bmn.y), ny);
+    k.iz = cell_coord((p.z - bmn.z) * nz / (bmx.z - bmn.z), nz);
   }
   float dx = dir.x, dy = dir.y, dz = dir.z;
   if (dx > 0) { k.tx_next = tx_min + (k.ix + 1) * k.dtx; k.ix_step = +1; k.ix_stop = nx; }

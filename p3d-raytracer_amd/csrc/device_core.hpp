@@ -572,9 +572,15 @@ __device__ inline bool grid_init(const DevGrid& G, const RayS& ray, GridWalk& k)
   k.dtz = (double)((tz_max - tz_min) / nz);
   F3 p = o;
   if (!is_inside(mn, mx, o)) p = o + dir * t0;
-  k.ix = (int)clampd((double)((p.x - mn.x) * nx / (mx.x - mn.x)), 0, nx - 1);
-  k.iy = (int)clampd((double)((p.y - mn.y) * ny / (mx.y - mn.y)), 0, ny - 1);
-  k.iz = (int)clampd((double)((p.z - mn.z) * nz / (mx.z - mn.z)), 0, nz - 1);
+  // clamp() passes a NaN through (0 * inf on a slab plane); the reference then dies in cells.at().
+  // Map it to cell 0 explicitly so that no lane can ever index outside the cell arrays.
+  auto coord = [](double v, int n) {
+    const double c = clampd(v, 0, n - 1);
+    return (c >= 0) ? (int)c : 0;
+  };
+  k.ix = coord((double)((p.x - mn.x) * nx / (mx.x - mn.x)), nx);
+  k.iy = coord((double)((p.y - mn.y) * ny / (mx.y - mn.y)), ny);
+  k.iz = coord((double)((p.z - mn.z) * nz / (mx.z - mn.z)), nz);
   if (dir.x > 0) { k.tx_next = tx_min + (k.ix + 1) * k.dtx; k.ix_step = 1; k.ix_stop = nx; }
   else           { k.tx_next = tx_min + (nx - k.ix) * k.dtx; k.ix_step = -1; k.ix_stop = -1; }
   if (dir.x == 0.0f) k.tx_next = FLT_MAX;

@@ -374,3 +374,33 @@ def test_skybox_requested_without_cubemap_is_an_error():
     dev, _ = _pair(scene_path("balls_low.p3f"), res=(32, 32), grid=False)
     with pytest.raises(p3d.P3DError):
         dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=1, skybox=1))
+
+
+@pytest.mark.parametrize("accel", [p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH])
+def test_axis_parallel_rays_and_nan_semantics(accel):
+    """scenes/axis_aligned.p3f: the centre ray is exactly (0,0,-1): inf in 1/d, NaN on slab planes, an
+    edge-on triangle (denominator 0 -> inv_denom inf -> NaN t reported as a hit, A10).  The wave that
+    holds such a lane must leave the v_max3/v_min3 fast path; results must still equal the oracle's."""
+    from conftest import ROOT
+    dev, sc = _pair(os.path.join(ROOT, "scenes", "axis_aligned.p3f"))
+    o, d = sc.primary_ray(64.5, 64.5)
+    assert d[0] == 0.0 and d[1] == 0.0 and d[2] == -1.0
+    cfg = p3d.whitted_config(accel=accel, max_depth=4, collect_stats=1)
+    rgb, hit, st = dev.render(cfg)
+    o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+    assert (hit == o_hit).all()
+    m = np.isfinite(o_rgb).all(-1)
+    assert (np.isfinite(rgb).all(-1) == m).all()              # NaN pixels (if any) are NaN on both sides
+    assert np.abs(rgb[m] - o_rgb[m]).max() <= 2e-6
+    assert (st.rays, st.node_tests, st.box_tests, st.tri_tests) == (o_st.rays, o_st.node_tests, o_st.box_tests, o_st.tri_tests)
+    # crafted queries: rays inside triangle planes, along box faces and edges, zero direction components
+    q_o = np.array([[0, 0, 5], [0, -3, 0.7], [0, 0, 5], [-1, -1, 5], [1, 0.5, 5], [0, 3, 1.0], [-3, 0, -1.5], [0.5, 0.5, 3]], np.float32)
+    q_d = np.array([[0, 0, -1], [0, 1, 0], [0, 0, -2], [0, 0, -1], [0, 0, -1], [0, -1, 0], [1, 0, 0], [0, 0, -1]], np.float32)
+    g_hit, g_hp = dev.trace_closest(accel, q_o, q_d)
+    c_hit, _, c_hp = sc.trace_closest(accel, q_o, q_d)
+    assert (g_hit == c_hit).all()
+    ok = g_hit >= 0
+    assert (np.isnan(g_hp[ok]) == np.isnan(c_hp[ok])).all()
+    fin = ok[:, None] & ~np.isnan(c_hp)
+    assert (g_hp[fin].view(np.uint32) == c_hp[fin].view(np.uint32)).all()
+    assert (dev.trace_any(accel, q_o, q_d) == sc.trace_any(accel, q_o, q_d)).all()
