@@ -5,7 +5,7 @@
 // runs ONE flat loop whose body is a single bounce; a lane whose path ended starts its next
 // sample (or pops its pending dielectric branch) in the same iteration instead of waiting
 // for the slowest lane of the wave, so the wave only idles lanes in the very last
-// iterations of a tile ("persistent threads", north_star).  Radiance is carried as
+// iterations of a tile (the "persistent threads" bounce loop BASELINE.json asks for).  Radiance is carried as
 //     L += T * (E + e);   T *= f
 // which is the same sum evaluated outermost-first (the recursion evaluates innermost-
 // first): results agree with the recursive oracle to float rounding (~1e-6 relative),
@@ -18,6 +18,10 @@
 #pragma once
 
 #include "kernels.hpp"
+
+#ifndef P3D_PT_WAVES
+#define P3D_PT_WAVES 3  // minimum waves per SIMD asked of the register allocator (2: 6.4 ms, 3: 5.6 ms, 4: 6.0 ms + spills on cornell 512x512x16spp)
+#endif
 
 namespace p3d {
 
@@ -55,7 +59,7 @@ struct Pending {
 };
 
 template <int ACCEL, bool LDS, bool STATS>
-__global__ void __launch_bounds__(kBlock) pt_kernel(const RenderParams P) {
+__global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderParams P) {
   extern __shared__ float4 smem[];
   uint32_t tx, ty;
   if (!tile_of_block(P, tx, ty)) return;
