@@ -404,3 +404,17 @@ def test_axis_parallel_rays_and_nan_semantics(accel):
     fin = ok[:, None] & ~np.isnan(c_hp)
     assert (g_hp[fin].view(np.uint32) == c_hp[fin].view(np.uint32)).all()
     assert (dev.trace_any(accel, q_o, q_d) == sc.trace_any(accel, q_o, q_d)).all()
+
+
+@pytest.mark.parametrize("scene", ["balls_high.p3f", "mount_high.p3f"])
+@pytest.mark.parametrize("accel", [p3d.ACCEL_GRID, p3d.ACCEL_BVH])
+def test_large_packaged_scenes(scene, accel):
+    """the big packaged scenes (7 381 spheres / 2 048 triangles, legacy `f` lines) as
+    BVH and grid stress inputs: too large for LDS staging, deep trees, many sphere re-normalisations."""
+    dev, sc = _pair(scene_path(scene), res=(160, 160), legacy=True)
+    cfg = p3d.whitted_config(accel=accel, max_depth=3, collect_stats=1)
+    rgb, hit, st = dev.render(cfg)
+    o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+    compare((rgb, hit), (o_rgb, o_hit), 2e-6)
+    assert (st.rays, st.node_tests, st.sphere_tests, st.tri_tests, st.max_stack) == \
+           (o_st.rays, o_st.node_tests, o_st.sphere_tests, o_st.tri_tests, o_st.max_stack)
