@@ -717,7 +717,8 @@ __device__ inline F3 skybox_color(const DevScene& sc, F3 d) {
   // u8tofloat, maths.h:89-92
   return f3((float)(px & 0xffu) / 255.99f, (float)((px >> 8) & 0xffu) / 255.99f, (float)((px >> 16) & 0xffu) / 255.99f);
 }
-// miss colour of main.cpp:144-147 / 350-355
+// miss colour of main.cpp:144-147 / 350-355.  Pass the KERNEL ARGUMENT copy of the scene (P.sc): the faces are
+// indexed dynamically, and indexing a local copy would force the whole struct into scratch memory.
 __device__ __forceinline__ F3 miss_color(const DevScene& sc, bool skybox, F3 raw_direction) {
   return skybox ? skybox_color(sc, raw_direction) : sc.bg;
 }

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
           const int obj = closest_hit<ACCEL, !LDS>(sc, st, ray, Pn, g, ct);
           if (level == 0 && si == 0 && sj == 0) first_hit = obj;
           if (obj < 0) {  // main.cpp:144-147
-            result = miss_color(sc, P.skybox != 0, ray.d);
+            result = miss_color(P.sc, P.skybox != 0, ray.d);
             break;
           }
           ct.add(kShadedHits);

@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
       const int obj = closest_hit<ACCEL, !LDS>(sc, st, ray, Pn, g, ct);
       if (first_ray) { first_hit = obj; first_ray = false; }
       if (obj < 0 || depth == 0) {  // main.cpp:350-355: the background acts as an environment light
-        L = L + T * miss_color(sc, P.skybox != 0, ray.d);
+        L = L + T * miss_color(P.sc, P.skybox != 0, ray.d);
         alive = false;
         continue;
       }
