@@ -418,3 +418,65 @@ def test_large_packaged_scenes(scene, accel):
     compare((rgb, hit), (o_rgb, o_hit), 2e-6)
     assert (st.rays, st.node_tests, st.sphere_tests, st.tri_tests, st.max_stack) == \
            (o_st.rays, o_st.node_tests, o_st.sphere_tests, o_st.tri_tests, o_st.max_stack)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_random_scenes_whitted(seed, tmp_path):
+    """Differential fuzzing: random spheres / triangles / boxes (/ planes for accel None), random opaque,
+    reflective and refractive materials, random camera (sometimes with a lens) and lights; every
+    accel; depth 5; no-AA and AA+soft-shadow+DOF variants."""
+    from fuzz_scenes import random_scene
+    path = random_scene(1000 + seed, str(tmp_path / "fuzz.p3f"), n_planes=1 if seed % 3 == 0 else 0)
+    dev, sc = _pair(path)
+    for accel in (p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH):
+        kw = dict(antialiasing=1, spp_sqrt=2, soft_shadows=1, depth_of_field=1, sample_disk=seed % 2, seed=seed) if seed % 4 == 1 else {}
+        cfg = p3d.whitted_config(accel=accel, max_depth=5, collect_stats=1, **kw)
+        rgb, hit, st = dev.render(cfg)
+        o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+        assert (hit == o_hit).all(), (seed, accel)
+        m = np.isfinite(o_rgb).all(-1)
+        assert (np.isfinite(rgb).all(-1) == m).all()
+        assert np.abs(rgb[m] - o_rgb[m]).max() <= 5e-6, (seed, accel)
+        assert (st.rays, st.node_tests, st.sphere_tests, st.tri_tests, st.box_tests, st.plane_tests) == \
+               (o_st.rays, o_st.node_tests, o_st.sphere_tests, o_st.tri_tests, o_st.box_tests, o_st.plane_tests), (seed, accel)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_random_scenes_path_tracer(seed, tmp_path):
+    from fuzz_scenes import random_scene
+    path = random_scene(2000 + seed, str(tmp_path / "fuzz_pt.p3f"), n_lights=0, emitters=1 + seed % 3, res=(64, 64))
+    dev, sc = _pair(path)
+    for accel in (p3d.ACCEL_NONE, p3d.ACCEL_BVH):
+        cfg = p3d.pathtrace_config(accel=accel, spp_sqrt=3, max_depth=12 + seed, dof=seed % 2, seed=seed, collect_stats=1)
+        rgb, hit, st = dev.render(cfg)
+        o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+        assert (hit == o_hit).all(), (seed, accel)
+        m = np.isfinite(o_rgb).all(-1)
+        assert (np.isfinite(rgb).all(-1) == m).all()
+        assert np.abs(rgb[m] - o_rgb[m]).max() <= TOL * max(1.0, float(np.abs(o_rgb[m]).max())), (seed, accel)
+        assert (st.rays_primary, st.rays_bounce, st.rays_light) == (o_st.rays_primary, o_st.rays_bounce, o_st.rays_light), (seed, accel)
+
+
+def test_bench_contract_json_line():
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline`."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["vs_baseline"] is None
+    assert d["config"]["rays_per_frame"] == 4944908 and "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert d["value"] > 100 * cb["value"]
