@@ -14,6 +14,20 @@ SCENES = os.path.join(GOLDEN, "scenes")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")
+    _ensure_built()
+
+
+def _ensure_built():
+    """The suites load two in-tree shared libraries.  Build whatever is missing or stale (hipcc
+    cross-compiles gfx950 without a GPU; g++ for the oracle) so that `pytest tests` works on a
+    fresh checkout without a separate build step."""
+    import subprocess
+    pkg = os.path.join(ROOT, "p3d-raytracer_amd")
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.check_call(["make", "-s", "-C", pkg, "libp3d.so"], stdout=subprocess.DEVNULL)
+    elif not os.path.exists(os.path.join(pkg, "libp3d.so")):
+        raise RuntimeError("p3d-raytracer_amd/libp3d.so is missing and hipcc is not available to build it")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libp3doracle.so"], stdout=subprocess.DEVNULL)
 
 
 def scene_path(name):
