@@ -4,7 +4,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -319,17 +318,6 @@ int finish_stats(p3d_scene* s, hipStream_t st, p3d_stats* stats) {
   stats->pixels = h[kPixels]; stats->max_stack = h[kMaxStack];
   return P3D_OK;
 }
-
-bool getenv_flag(const char* name) {
-  const char* v = std::getenv(name);
-  return v && *v && *v != '0';
-}
-int getenv_int(const char* name, int dflt) {
-  const char* v = std::getenv(name);
-  return (v && *v) ? std::atoi(v) : dflt;
-}
-
-
 
 }  // namespace
 
