@@ -122,8 +122,9 @@ def main():
     handles = [None, None]
     pick = (lambda pair: pair[1]) if args.gather == "u8" else (lambda pair: pair[0])
     gdev = "cpu" if host_staged else "cuda"
+    # (every rank keeps receive buffers: only rank 0 uses them unless the backend forces all_gather)
     gathered = ([[torch.empty(pick(bufs[0]).shape, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
-                if (world > 1 and rank == 0) else None)
+                if world > 1 else None)
     frame8 = torch.empty((res, res, 3), dtype=torch.uint8, device=gdev) if rank == 0 and world > 1 else None
     frame_rgb = torch.empty((res, res, 3), dtype=torch.float32, device=gdev) if rank == 0 and world > 1 else None
     frame_hit = torch.empty((res, res), dtype=torch.int32, device=gdev) if rank == 0 and world > 1 else None
@@ -157,8 +158,8 @@ def main():
             ev_pairs.append((e0, e1))
         if world > 1:
             payload = pick(bufs[slot]).cpu() if host_staged else pick(bufs[slot])
-            handles[slot], _ = p3d.gather_frame(payload, (res, res), rank, world, stripe_h, 0,
-                                                gathered[slot] if rank == 0 else None, async_op=True)
+            handles[slot], _ = p3d.gather_frame(payload, (res, res), rank, world, stripe_h, 0, gathered[slot],
+                                                async_op=True)
 
     def drain():
         for slot in (0, 1):

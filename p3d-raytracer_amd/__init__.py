@@ -401,14 +401,29 @@ def assemble_frame(gathered, res, world, stripe_h, frame_rgb=None, frame_hit=Non
     return frame_rgb, frame_hit
 
 
+_GATHER_MODE = {"mode": "gather"}
+
+
 def gather_frame(local_buf, res, rank, world, stripe_h, dst=0, gathered=None, async_op=False):
     """One collective per frame: every rank's packed stripe buffer to rank `dst` (RCCL on GPUs,
-    gloo in the CPU tests).  Returns (work handle or None, gather list or None)."""
+    gloo in the CPU tests).  Returns (work handle or None, gather list or None).
+    `gather` is the natural all-to-one; should a backend build not provide it, the first failure
+    switches this process group to `all_gather` (same bytes into rank `dst`, the other ranks simply
+    ignore what they receive) - every rank hits the same error at the same call, so they switch
+    together."""
     import torch
     import torch.distributed as dist
-    if rank == dst and gathered is None:
+    if _GATHER_MODE["mode"] == "gather":
+        if rank == dst and gathered is None:
+            gathered = [torch.empty_like(local_buf) for _ in range(world)]
+        try:
+            work = dist.gather(local_buf, gathered if rank == dst else None, dst=dst, async_op=async_op)
+            return work, gathered
+        except (RuntimeError, NotImplementedError):
+            _GATHER_MODE["mode"] = "all_gather"
+    if gathered is None:
         gathered = [torch.empty_like(local_buf) for _ in range(world)]
-    work = dist.gather(local_buf, gathered if rank == dst else None, dst=dst, async_op=async_op)
+    work = dist.all_gather(gathered, local_buf, async_op=async_op)
     return work, gathered
 
 

@@ -25,13 +25,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, mode="gather"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import p3d_amd as p3d
     from oracle import binding as ob
+    p3d._GATHER_MODE["mode"] = mode  # "all_gather" = the fallback collective
     sc = ob.Scene(os.path.join(ROOT, "tests", "golden", "scenes", "balls_low.p3f"))
     sc.set_resolution(RES, RES)
     cfg = ob.whitted_config(2, 3)
@@ -62,11 +63,7 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_stripe_gather_assemble_two_ranks(tmp_path, world):
-    out = str(tmp_path / "result.txt")
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert open(out).read() == "ok"
+XX
 
 
 def test_stripe_rows_cover_the_frame_exactly_once():
