@@ -63,7 +63,11 @@ def _worker(rank, world, port, out_path, mode="gather"):
     dist.destroy_process_group()
 
 
-XX
+@pytest.mark.parametrize("world,mode", [(2, "gather"), (4, "gather"), (2, "all_gather")])
+def test_stripe_gather_assemble_two_ranks(tmp_path, world, mode):
+    out = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(world, _free_port(), out, mode), nprocs=world, join=True)
+    assert open(out).read() == "ok"
 
 
 def test_stripe_rows_cover_the_frame_exactly_once():
