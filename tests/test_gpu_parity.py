@@ -480,3 +480,20 @@ def test_bench_contract_json_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > 100 * cb["value"]
+
+
+def test_pow_spec_matches_libm_after_float_rounding(tmp_path):
+    """pow_spec (device_core.hpp) replaces libm's double pow of main.cpp:224 in the kernels; only its
+    float-rounded value is observable.  2M inputs (x in [0,1], the packaged shine values and random
+    exponents): relative error < 1e-12 and at most a handful of float roundings different from libm."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "pow_check")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "p3d-raytracer_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "pow_spec_check.hip"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    m = re.search(r"worst_rel=([0-9.e+-]+) float_mismatches=(\d+)", out)
+    assert m, out
+    assert float(m.group(1)) < 1e-12 and int(m.group(2)) <= 4, out
