@@ -222,7 +222,21 @@ int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
   v.cam.aperture = c.aperture; v.cam.res_x = c.res_x; v.cam.res_y = c.res_y;
   v.bg = to_f3(d->background);
   s->has_bvh = d->n_bvh_nodes > 0;
-  s->bvh_max_depth = d->bvh_max_depth;
+  // The node-stack capacity (LDS + spill) is derived from the tree depth: never trust the caller's
+  // number below what the node array really contains (child indices were validated above:
+  // children lie behind their parent, so this walk terminates).
+  uint32_t real_depth = d->n_bvh_nodes ? 1 : 0;
+  if (d->n_bvh_nodes) {
+    std::vector<uint32_t> level(d->n_bvh_nodes, 0);
+    level[0] = 1;
+    for (uint32_t i = 0; i < d->n_bvh_nodes; ++i) {
+      const p3d_bvh_node& n = d->bvh_nodes[i];
+      if (level[i] == 0) continue;  // unreachable record
+      real_depth = std::max(real_depth, level[i]);
+      if (!(n.count_leaf & P3D_BVH_LEAF)) level[n.index] = level[n.index + 1] = level[i] + 1;
+    }
+  }
+  s->bvh_max_depth = std::max(d->bvh_max_depth, real_depth);
   if (d->has_grid) {
     const p3d_grid_desc& g = d->grid;
     P3D_HIP(hipMalloc((void**)&s->d_cell_start, (size_t)(g.n_cells + 1) * 4));

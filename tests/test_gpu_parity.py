@@ -497,3 +497,45 @@ def test_pow_spec_matches_libm_after_float_rounding(tmp_path):
     m = re.search(r"worst_rel=([0-9.e+-]+) float_mismatches=(\d+)", out)
     assert m, out
     assert float(m.group(1)) < 1e-12 and int(m.group(2)) <= 4, out
+
+
+def test_scene_create_rejects_malformed_descriptors():
+    """Every index a lane can follow is validated on upload (a wild index in a kernel could take the
+    whole host down): corrupt one field at a time and expect P3D_ERR_INVALID / CAPACITY, never a crash.
+    A too-small bvh_max_depth is corrected from the node array (the stack capacity depends on it)."""
+    import ctypes as C
+    hs = p3d.HostScene(scene_path("balls_low.p3f"))
+    good = hs.desc(bvh=True, grid=True)
+    L = p3d.lib()
+
+    def try_create(mutate):
+        d = p3d.SceneDesc.from_buffer_copy(bytes(good))
+        nodes = (p3d.BvhNode * good.n_bvh_nodes)(*[good.bvh_nodes[i] for i in range(good.n_bvh_nodes)])
+        order = (C.c_uint32 * good.n_bvh_prim_index)(*[good.bvh_prim_index[i] for i in range(good.n_bvh_prim_index)])
+        prims = (p3d.Prim * good.n_prims)(*[good.prims[i] for i in range(good.n_prims)])
+        items = (C.c_uint32 * good.grid.n_items)(*[good.grid.cell_items[i] for i in range(good.grid.n_items)])
+        d.bvh_nodes, d.bvh_prim_index, d.prims = nodes, order, prims
+        d.grid.cell_items = items
+        mutate(d, nodes, order, prims, items)
+        h = C.c_void_p()
+        rc = L.p3d_scene_create(C.byref(d), 0, C.byref(h))
+        if rc == 0:
+            L.p3d_scene_destroy(h)
+        return rc
+
+    assert try_create(lambda d, n, o, p, it: None) == 0
+    bad = [
+        lambda d, n, o, p, it: setattr(p[3], "material", 99),
+        lambda d, n, o, p, it: setattr(p[0], "type", 7),
+        lambda d, n, o, p, it: setattr(n[0], "index", 1000),        # child pair beyond the array
+        lambda d, n, o, p, it: setattr(n[4], "index", 1),           # child in front of its parent (cycle)
+        lambda d, n, o, p, it: setattr(o, "_x", None) or o.__setitem__(0, 500),   # object index out of range
+        lambda d, n, o, p, it: it.__setitem__(0, 12345),            # grid item out of range
+        lambda d, n, o, p, it: setattr(d, "n_bvh_prim_index", 3),
+        lambda d, n, o, p, it: setattr(d, "abi_version", 99),
+    ]
+    for i, m in enumerate(bad):
+        rc = try_create(m)
+        assert rc in (-1, -4), (i, rc)
+    # wrong depth hint: accepted, corrected internally, rendering still matches
+    assert try_create(lambda d, n, o, p, it: setattr(d, "bvh_max_depth", 1)) == 0
