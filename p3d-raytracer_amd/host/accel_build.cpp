@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <memory>
+#include <thread>
 
 namespace p3d {
 
@@ -31,42 +33,60 @@ void BVH::build(const std::vector<Object*>& objects) {
   nodes_.clear();
   nodes_.reserve(2 * n + 1);
   max_depth_ = 0;
+  box_.resize(n);
+  centroid_.resize(n);
+  keys_.resize(n);
 
   AABB all = AABB::empty();
   for (size_t i = 0; i < n; ++i) {
-    all.extend(objs_[i]->GetBoundingBox());
+    box_[i] = objs_[i]->GetBoundingBox();
+    centroid_[i] = objs_[i]->getCentroid();
+    all.extend(box_[i]);
     order_[i] = static_cast<uint32_t>(i);
   }
   p3d_bvh_node root{};
   put3(root.bmin, all.min);
   put3(root.bmax, all.max);
   nodes_.push_back(root);
-  split(0, static_cast<int>(n), 0, 1);
+
+  const unsigned hw = std::thread::hardware_concurrency();
+  Top top{root, 0, static_cast<int>(n), 1, nullptr, nullptr, {}, 0};
+  // Subtrees own disjoint ranges of order_/keys_, so they are built side by side (each split
+  // hands its left half to a new thread while there is fork budget); only the node numbering
+  // is sequential (children are appended when their parent splits, the whole left subtree
+  // before the right one, bvh.cpp:185-194) and is done afterwards by emit_top().
+  int forks = 0;
+  if (n >= kParallelMin && hw > 1)
+    while ((2u << forks) <= std::min(hw, 32u)) ++forks;
+  grow_top(top, forks);
+  emit_top(top, 0);
+  box_.clear(); box_.shrink_to_fit();
+  centroid_.clear(); centroid_.shrink_to_fit();
+  keys_.clear(); keys_.shrink_to_fit();
 }
 
-void BVH::split(int first, int last, uint32_t node, uint32_t level) {
-  if (level > max_depth_) max_depth_ = level;
+// One split decision (bvh.cpp:119-161): sorts order_[first,last) and returns the cut slot.
+int BVH::partition(const p3d_bvh_node& box, int first, int last, p3d_bvh_node& l, p3d_bvh_node& r) {
   const int count = last - first;
-  if (count <= Threshold) {
-    nodes_[node].index = static_cast<uint32_t>(first);
-    nodes_[node].count_leaf = P3D_BVH_LEAF | static_cast<uint32_t>(count);
-    return;
-  }
-  const Vector lo(nodes_[node].bmin[0], nodes_[node].bmin[1], nodes_[node].bmin[2]);
-  const Vector hi(nodes_[node].bmax[0], nodes_[node].bmax[1], nodes_[node].bmax[2]);
+  const Vector lo(box.bmin[0], box.bmin[1], box.bmin[2]);
+  const Vector hi(box.bmax[0], box.bmax[1], box.bmax[2]);
   const Vector extent = hi - lo;
   int axis = 2;
   if (extent.x >= extent.y && extent.x >= extent.z) axis = 0;
   else if (extent.y >= extent.x && extent.y >= extent.z) axis = 1;
 
-  auto centre_of_box = [&](uint32_t id) {
-    const AABB b = objs_[id]->GetBoundingBox();
-    return (b.max.getIndex(axis) + b.min.getIndex(axis)) * 0.5f;
-  };
-  std::sort(order_.begin() + first, order_.begin() + last,
-            [&](uint32_t a, uint32_t b) { return centre_of_box(a) < centre_of_box(b); });
+  // The comparator's value for every object of the range, next to its id: std::sort sees the
+  // same sequence of comparison outcomes as when it sorts the objects themselves, so the
+  // permutation (ties included) is the same.
+  for (int s = first; s < last; ++s) {
+    const uint32_t id = order_[s];
+    keys_[s].key = (box_[id].max.getIndex(axis) + box_[id].min.getIndex(axis)) * 0.5f;
+    keys_[s].id = id;
+  }
+  std::sort(keys_.begin() + first, keys_.begin() + last, [](const SortKey& a, const SortKey& b) { return a.key < b.key; });
+  for (int s = first; s < last; ++s) order_[s] = keys_[s].id;
 
-  auto centroid = [&](int slot) { return objs_[order_[slot]]->getCentroid().getIndex(axis); };
+  auto centroid = [&](int slot) { return centroid_[order_[slot]].getIndex(axis); };
   auto one_side_empty = [&](float c) { return centroid(first) > c || centroid(last - 1) <= c; };
 
   float cut = static_cast<float>(static_cast<double>(hi.getIndex(axis) + lo.getIndex(axis)) * 0.5);
@@ -84,19 +104,75 @@ void BVH::split(int first, int last, uint32_t node, uint32_t level) {
   }
 
   AABB left = AABB::empty(), right = AABB::empty();
-  for (int s = first; s < mid; ++s) left.extend(objs_[order_[s]]->GetBoundingBox());
-  for (int s = mid; s < last; ++s) right.extend(objs_[order_[s]]->GetBoundingBox());
-
-  const uint32_t child = static_cast<uint32_t>(nodes_.size());
-  nodes_[node].index = child;
-  nodes_[node].count_leaf = 0;
-  p3d_bvh_node l{}, r{};
+  for (int s = first; s < mid; ++s) left.extend(box_[order_[s]]);
+  for (int s = mid; s < last; ++s) right.extend(box_[order_[s]]);
+  l = p3d_bvh_node{};
+  r = p3d_bvh_node{};
   put3(l.bmin, left.min); put3(l.bmax, left.max);
   put3(r.bmin, right.min); put3(r.bmax, right.max);
-  nodes_.push_back(l);
-  nodes_.push_back(r);
-  split(first, mid, child, level + 1);
-  split(mid, last, child + 1, level + 1);
+  return mid;
+}
+
+// Recursive build of one (sub)tree into `nodes` (indices local to that vector); returns its
+// deepest level.
+uint32_t BVH::split(std::vector<p3d_bvh_node>& nodes, int first, int last, uint32_t node, uint32_t level) {
+  const int count = last - first;
+  if (count <= Threshold) {
+    nodes[node].index = static_cast<uint32_t>(first);
+    nodes[node].count_leaf = P3D_BVH_LEAF | static_cast<uint32_t>(count);
+    return level;
+  }
+  p3d_bvh_node l, r;
+  const int mid = partition(nodes[node], first, last, l, r);
+  const uint32_t child = static_cast<uint32_t>(nodes.size());
+  nodes[node].index = child;
+  nodes[node].count_leaf = 0;
+  nodes.push_back(l);
+  nodes.push_back(r);
+  const uint32_t dl = split(nodes, first, mid, child, level + 1);
+  const uint32_t dr = split(nodes, mid, last, child + 1, level + 1);
+  return dl > dr ? dl : dr;
+}
+
+// Split `t` and fork while `forks` > 0; below that, build the subtree into t.sub.
+void BVH::grow_top(Top& t, int forks) {
+  if (forks <= 0 || t.last - t.first <= static_cast<int>(kParallelMin / 4)) {
+    t.sub.reserve(2 * static_cast<size_t>(t.last - t.first) + 1);
+    t.sub.push_back(t.box);
+    t.depth = split(t.sub, t.first, t.last, 0, t.level);
+    return;
+  }
+  p3d_bvh_node l, r;
+  const int mid = partition(t.box, t.first, t.last, l, r);
+  t.left.reset(new Top{l, t.first, mid, t.level + 1, nullptr, nullptr, {}, 0});
+  t.right.reset(new Top{r, mid, t.last, t.level + 1, nullptr, nullptr, {}, 0});
+  std::thread other([&] { grow_top(*t.left, forks - 1); });
+  grow_top(*t.right, forks - 1);
+  other.join();
+}
+
+// Number the nodes as the recursive build does.
+void BVH::emit_top(Top& t, uint32_t node) {
+  if (t.left) {
+    const uint32_t child = static_cast<uint32_t>(nodes_.size());
+    nodes_[node].index = child;
+    nodes_[node].count_leaf = 0;
+    nodes_.push_back(t.left->box);
+    nodes_.push_back(t.right->box);
+    emit_top(*t.left, child);
+    emit_top(*t.right, child + 1);
+    return;
+  }
+  if (t.depth > max_depth_) max_depth_ = t.depth;
+  const uint32_t shift = static_cast<uint32_t>(nodes_.size()) - 1;  // sub[1] lands at nodes_.size()
+  auto place = [&](p3d_bvh_node nd) {
+    if (!(nd.count_leaf & P3D_BVH_LEAF)) nd.index += shift;
+    return nd;
+  };
+  nodes_[node] = place(t.sub[0]);
+  for (size_t i = 1; i < t.sub.size(); ++i) nodes_.push_back(place(t.sub[i]));
+  t.sub.clear();
+  t.sub.shrink_to_fit();
 }
 
 // ---------------------------------------------------------------------------

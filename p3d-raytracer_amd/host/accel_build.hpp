@@ -8,6 +8,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "p3d.h"
@@ -24,10 +25,26 @@ class BVH {
   uint32_t maxDepth() const { return max_depth_; }
 
  private:
-  void split(int first, int last, uint32_t node, uint32_t level);
+  struct SortKey { float key; uint32_t id; };
+  struct Top {  // a node of the part of the tree that is split before the subtree builds start
+    p3d_bvh_node box;
+    int first, last;
+    uint32_t level;
+    std::unique_ptr<Top> left, right;  // both null: a subtree, built into `sub`
+    std::vector<p3d_bvh_node> sub;     // its nodes, indices local
+    uint32_t depth;
+  };
+  int partition(const p3d_bvh_node& box, int first, int last, p3d_bvh_node& l, p3d_bvh_node& r);
+  uint32_t split(std::vector<p3d_bvh_node>& nodes, int first, int last, uint32_t node, uint32_t level);
+  void grow_top(Top& t, int forks);
+  void emit_top(Top& t, uint32_t node);
   static constexpr int Threshold = 2;  // bvh.cpp:83
+  static constexpr size_t kParallelMin = 8192;   // below this the build is a single recursion
   std::vector<Object*> objs_;
   std::vector<uint32_t> order_;
+  std::vector<AABB> box_;          // build-time caches of the virtual calls, dropped after build()
+  std::vector<Vector> centroid_;
+  std::vector<SortKey> keys_;
   std::vector<p3d_bvh_node> nodes_;
   uint32_t max_depth_ = 0;
 };
