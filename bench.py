@@ -32,6 +32,9 @@ def parse():
                     help="cfg2 (default) = BASELINE configs[1]; cfg3/cfg4/cfg5 = configs[2]/[3]/[4] at their full sizes; "
                          "tri100k / cornell_pt = the same scenes at quick sizes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-order", default="cost", choices=["cost", "frame"],
+                    help="p3d_config.tile_order: cost = tiles most-expensive-class first (schedule recorded by the first "
+                         "launch, i.e. during warmup); frame = image order.  Scheduling only, same bits either way.")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production).  gloo stages the gather through host memory: only for "
                          "rehearsing the N>1 code path with several ranks on ONE GPU")
@@ -98,6 +101,7 @@ def main():
     host_staged = world > 1 and args.backend == "gloo"
 
     scene_path, cfg, base, desc = workload_setup(args.workload, world, p3d)
+    cfg.tile_order = p3d.TILE_ORDER_COST if args.tile_order == "cost" else p3d.TILE_ORDER_FRAME
     stripe_h = 8
     fixed = base < 0  # negative base: fixed frame size (strong scaling)
     base = abs(base)
@@ -234,6 +238,7 @@ def main():
             "config": {"workload": desc, "resolution": [res, res], "rays_per_frame": int(rays_total),
                        "ray_definition": "one traversal query (closest-hit or any-hit)",
                        "outputs_per_rank": "float RGB + hit ID (16 B/px) + u8 image (3 B/px), all written to HBM",
+                       "tile_order": args.tile_order,
                        "parallelism": "image rows in %d-row stripes, round-robin over %d GPU(s)%s"
                                       % (stripe_h, world,
                                          "; one RCCL gather per frame of the %s to rank 0, double-buffered; "

@@ -175,6 +175,13 @@ typedef struct p3d_scene_desc {
 /* Runtime form of the compile-time options of constants.h:6-45.  p3d_config_default()
  * fills in the reference's shipped values, except SKYBOX: it defaults to 0 (miss = bclr)
  * because the cubemap has to be supplied separately (p3d_scene_set_skybox). */
+/* Order in which the 8x8-pixel tiles of a launch are handed to the GPU.  COST (default, 0):
+ * tiles whose pixels spawn reflection / refraction chains go first, so the long-running
+ * tiles do not end up alone at the end of the frame; the order comes from a small estimate
+ * pass that is memoised per (scene, max_depth, accel, tile).  FRAME: image order. */
+#define P3D_TILE_ORDER_COST 0u
+#define P3D_TILE_ORDER_FRAME 1u
+
 typedef struct p3d_config {
   uint32_t integrator;    /* PATHTRACING        constants.h:36  */
   uint32_t accel;         /* acl_str            constants.h:44  */
@@ -190,7 +197,7 @@ typedef struct p3d_config {
   uint32_t collect_stats; /* 1: fill the test/ray counters of p3d_stats (slower kernel) */
   uint32_t skybox;        /* SKYBOX             constants.h:30: a miss returns the cubemap texel
                              (main.cpp:145,351) instead of bclr; needs p3d_scene_set_skybox */
-  uint32_t reserved;
+  uint32_t tile_order;    /* P3D_TILE_ORDER_*: scheduling only, never changes a result */
   uint64_t seed;          /* replaces set_rand_seed(time*time), main.cpp:722:
                              every (pixel, sample) draws from its own stream */
 } p3d_config;

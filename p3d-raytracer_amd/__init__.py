@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("P3D_LIB") or os.path.join(HERE, "libp3d.so")  # P3D_L
 
 ACCEL_NONE, ACCEL_GRID, ACCEL_BVH = 0, 1, 2
 WHITTED, PATHTRACE = 0, 1
+TILE_ORDER_COST, TILE_ORDER_FRAME = 0, 1
 SAMPLE_JITTER, SAMPLE_TENT = 0, 1
 LOAD_LEGACY_F11 = 1
 
@@ -89,7 +90,7 @@ class Config(C.Structure):
                 ("spp_sqrt", C.c_uint32), ("antialiasing", C.c_uint32), ("depth_of_field", C.c_uint32),
                 ("sample_disk", C.c_uint32), ("soft_shadows", C.c_uint32), ("sample_mode", C.c_uint32),
                 ("light_side", C.c_float), ("gamma", C.c_float), ("collect_stats", C.c_uint32),
-                ("skybox", C.c_uint32), ("reserved", C.c_uint32), ("seed", C.c_uint64)]
+                ("skybox", C.c_uint32), ("tile_order", C.c_uint32), ("seed", C.c_uint64)]
 
 
 class SkyboxFace(C.Structure):

@@ -21,6 +21,23 @@
 
 namespace p3d {
 
+#ifdef P3D_TIMELINE  // debug builds only (build/variants): per-workgroup start/end clock + HW id
+__device__ unsigned long long* g_timeline = nullptr;
+#define P3D_TL_BEGIN() const unsigned long long tl_t0 = wall_clock64();
+#define P3D_TL_END()                                                                                  \
+  if (g_timeline && threadIdx.x == 0) {                                                               \
+    g_timeline[3 * (size_t)blockIdx.x] = tl_t0;                                                       \
+    g_timeline[3 * (size_t)blockIdx.x + 1] = wall_clock64();                                          \
+    g_timeline[3 * (size_t)blockIdx.x + 2] =                                                          \
+        ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); \
+  }
+#else
+#define P3D_TL_BEGIN()
+#define P3D_TL_END()
+#endif
+
+constexpr int kSchedClasses = 4;
+
 struct RenderParams {
   DevScene sc;
   const float4* blob;   // all float4 scene arrays, contiguous (for the LDS staging copy)
@@ -47,6 +64,10 @@ struct RenderParams {
   uint2* spill;               // node-stack overflow area, [entry - stack_cap][thread]
   int32_t stack_cap;          // node-stack entries per lane held in LDS
   uint32_t lds_scene_f4;      // float4s reserved for the staged scene (0 when not staged)
+  // Cost-ordered tile schedule (DESIGN.md "Tile schedule"); both null: frame order, nothing recorded.
+  //   sched: see sched_build_kernel.   tile_cost[t]: wall-clock ticks the workgroup of tile t was resident.
+  const uint32_t* sched;
+  uint32_t* tile_cost;
 };
 
 // LDS map of one workgroup:  [ staged scene (lds_scene_f4 float4) | node stack (cap * 64 * 8 B) | pending (PT) ]
@@ -70,14 +91,65 @@ __device__ __forceinline__ void stage_scene(DevScene& sc, const RenderParams& P,
 // robin: each XCD's L2 sees spatially coherent rays (matters for the 8.8 MB scene, which
 // does not fit one 4 MiB L2) while expensive and cheap image regions are still spread over
 // all XCDs.  xcd_chunk = 1 is the identity map (LDS-staged scenes have no L2 working set).
+//
+// With a schedule (DESIGN.md "Tile schedule") blockIdx order is "most expensive class first":
+// workgroups are dispatched in blockIdx order, so the few long-running tiles start at once and
+// the many short ones fill in behind them instead of the other way round.
 __device__ __forceinline__ bool tile_of_block(const RenderParams& P, uint32_t& tx, uint32_t& ty) {
   const uint32_t b = blockIdx.x;
-  const uint32_t j = b >> 3;
-  const uint32_t tile = ((j / P.xcd_chunk) * 8 + (b & 7u)) * P.xcd_chunk + (j % P.xcd_chunk);
-  if (tile >= P.tiles_x * P.tiles_y) return false;
+  const uint32_t n = P.tiles_x * P.tiles_y;
+  uint32_t tile;
+  if (P.sched) {
+    if (b >= n) return false;
+    uint32_t i = b;
+    int c = kSchedClasses - 1;
+    for (; c > 0; --c) {
+      const uint32_t in_class = P.sched[c];
+      if (i < in_class) break;
+      i -= in_class;
+    }
+    tile = P.sched[kSchedClasses + (uint32_t)c * n + i];
+  } else {
+    const uint32_t j = b >> 3;
+    tile = ((j / P.xcd_chunk) * 8 + (b & 7u)) * P.xcd_chunk + (j % P.xcd_chunk);
+    if (tile >= n) return false;
+  }
   tx = tile % P.tiles_x;
   ty = tile / P.tiles_x;
   return true;
+}
+
+// Cost of a finished tile, for the schedule of the following launches.
+__device__ __forceinline__ void record_tile_cost(const RenderParams& P, uint32_t tx, uint32_t ty, unsigned long long t_begin) {
+  if (P.tile_cost && threadIdx.x == 0) P.tile_cost[ty * P.tiles_x + tx] = (uint32_t)(wall_clock64() - t_begin);
+}
+
+// One workgroup: files every tile under a cost class relative to the mean cost of the launch
+// (>= 4x, >= 2x, >= 1.25x, rest).  sched layout, n tiles: [0..4) tiles per class, then the tiles
+// of class c from kSchedClasses + c * n.
+constexpr int kSchedBuildThreads = 1024;
+__host__ __device__ constexpr uint32_t sched_words(uint32_t n) { return kSchedClasses * (n + 1u); }
+
+__global__ void __launch_bounds__(kSchedBuildThreads) sched_build_kernel(const uint32_t* cost, uint32_t n, uint32_t* sched) {
+  __shared__ unsigned long long total;
+  __shared__ uint32_t count[kSchedClasses];
+  if (threadIdx.x == 0) total = 0;
+  if (threadIdx.x < kSchedClasses) count[threadIdx.x] = 0;
+  __syncthreads();
+  unsigned long long mine = 0;
+  for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) mine += cost[t];
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
+  __syncthreads();
+  const float mean = (float)total / (float)n;
+  for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) {
+    const float c = (float)cost[t];
+    const uint32_t cls = c >= 4.0f * mean ? 3u : (c >= 2.0f * mean ? 2u : (c >= 1.25f * mean ? 1u : 0u));
+    const uint32_t slot = atomicAdd(&count[cls], 1u);
+    sched[kSchedClasses + cls * n + slot] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < kSchedClasses) sched[threadIdx.x] = count[threadIdx.x];
 }
 
 template <bool STATS>
@@ -147,6 +219,8 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
   extern __shared__ float4 smem[];
   uint32_t tx, ty;
   if (!tile_of_block(P, tx, ty)) return;
+  P3D_TL_BEGIN()
+  const unsigned long long t_begin = P.tile_cost ? wall_clock64() : 0;
   DevScene sc = P.sc;
   stage_scene<LDS>(sc, P, smem);
 
@@ -311,6 +385,8 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
     }
   }
   if (STATS) flush_stats<STATS>(ct, P.stats);
+  record_tile_cost(P, tx, ty, t_begin);
+  P3D_TL_END()
 }
 
 // ---------------------------------------------------------------------------

@@ -49,10 +49,31 @@ struct Scratch {
   }
 };
 
+// One memoised tile schedule.  The cost of a tile is a function of the scene (camera included),
+// the chain depth, the back end, the sampling and the pixel rectangle: the first launch with a
+// given key runs in frame order and records what every tile cost, the launches after it take
+// the tiles most-expensive-class first.
+struct SchedEntry {
+  uint32_t accel = 0, aa = 0, spp = 0;
+  int32_t max_depth = 0, x0 = 0, y0 = 0, w = 0, h = 0, stripe_h = 0, stripe_stride = 0;
+  Scratch cost, sched;
+  hipEvent_t ready = nullptr;
+  hipStream_t built_on = nullptr;
+  uint64_t last_use = 0;
+  bool same_key(const SchedEntry& o) const {
+    return accel == o.accel && aa == o.aa && spp == o.spp && max_depth == o.max_depth && x0 == o.x0 && y0 == o.y0 &&
+           w == o.w && h == o.h && stripe_h == o.stripe_h && stripe_stride == o.stripe_stride;
+  }
+};
+constexpr size_t kSchedCacheEntries = 16;
+constexpr uint32_t kSchedMinTiles = 8192;  // with fewer tiles than ~2 per wave slot nearly all start at once anyway
+
 }  // namespace
 
 struct p3d_scene {
   int device = 0;
+  std::vector<SchedEntry> sched;
+  uint64_t sched_clock = 0;
   float4* d_blob = nullptr;
   uint32_t blob_f4 = 0;
   uint32_t off_nodes = 0, off_bgeom = 0, off_ogeom = 0, off_normals = 0, off_mats = 0, off_lights = 0;
@@ -87,6 +108,11 @@ void p3d_scene_destroy(p3d_scene* s) {
   if (s->d_emitters) (void)hipFree(s->d_emitters);
   if (s->d_stats) (void)hipFree(s->d_stats);
   for (uint32_t*& f : s->d_sky) if (f) (void)hipFree(f);
+  for (SchedEntry& e : s->sched) {
+    e.cost.release();
+    e.sched.release();
+    if (e.ready) (void)hipEventDestroy(e.ready);
+  }
   s->levels.release(); s->spill.release(); s->out_rgb.release(); s->out_hit.release();
   s->out_rgb8.release(); s->q_in.release(); s->q_out.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -300,6 +326,53 @@ hipError_t launch_accel(bool pt, bool aa, bool lds_scene, bool stats, const Rend
   return stats ? launch_one<ACCEL, false, true>(pt, aa, P, blocks, lds, st) : launch_one<ACCEL, false, false>(pt, aa, P, blocks, lds, st);
 }
 
+// Looks up the schedule for the launch described by (cfg, P).  Known key: P.sched is set.  New
+// key: P.tile_cost is set so that this launch (in frame order) records the costs, and *fresh
+// points at the entry, to be completed by schedule_finish() right after the launch.
+int schedule_lookup(p3d_scene* s, const p3d_config* cfg, RenderParams& P, hipStream_t st, SchedEntry** fresh) {
+  *fresh = nullptr;
+  SchedEntry key;
+  key.accel = cfg->accel; key.aa = cfg->antialiasing ? 1 : 0; key.spp = cfg->antialiasing ? cfg->spp_sqrt : 1;
+  key.max_depth = P.max_depth; key.x0 = P.x0; key.y0 = P.y0; key.w = P.w; key.h = P.h;
+  key.stripe_h = P.stripe_h; key.stripe_stride = P.stripe_stride;
+  for (SchedEntry& c : s->sched)
+    if (c.same_key(key)) {
+      if (c.built_on != st) P3D_HIP(hipStreamWaitEvent(st, c.ready, 0));
+      c.last_use = ++s->sched_clock;
+      P.sched = (const uint32_t*)c.sched.p;
+      return P3D_OK;
+    }
+  SchedEntry* e = nullptr;
+  if (s->sched.size() < kSchedCacheEntries) {
+    s->sched.emplace_back();
+    e = &s->sched.back();
+  } else {  // recycle the least recently used entry once the work queued with it has drained
+    e = &s->sched[0];
+    for (SchedEntry& c : s->sched)
+      if (c.last_use < e->last_use) e = &c;
+    P3D_HIP(hipDeviceSynchronize());
+  }
+  const uint32_t n = P.tiles_x * P.tiles_y;
+  if (int rc = e->cost.ensure((size_t)n * sizeof(uint32_t))) return rc;
+  if (int rc = e->sched.ensure((size_t)sched_words(n) * sizeof(uint32_t))) return rc;
+  if (!e->ready) P3D_HIP(hipEventCreateWithFlags(&e->ready, hipEventDisableTiming));
+  e->accel = key.accel; e->aa = key.aa; e->spp = key.spp; e->max_depth = key.max_depth; e->x0 = key.x0; e->y0 = key.y0;
+  e->w = key.w; e->h = key.h; e->stripe_h = key.stripe_h; e->stripe_stride = key.stripe_stride;
+  P.tile_cost = (uint32_t*)e->cost.p;
+  *fresh = e;
+  return P3D_OK;
+}
+
+int schedule_finish(p3d_scene* s, SchedEntry* e, uint32_t n_tiles, hipStream_t st) {
+  hipLaunchKernelGGL(sched_build_kernel, dim3(1), dim3(kSchedBuildThreads), 0, st, (const uint32_t*)e->cost.p, n_tiles, (uint32_t*)e->sched.p);
+  if (hipError_t err = hipGetLastError(); err != hipSuccess)
+    return fail(P3D_ERR_NO_DEVICE, std::string("schedule kernel launch: ") + hipGetErrorString(err));
+  P3D_HIP(hipEventRecord(e->ready, st));
+  e->built_on = st;
+  e->last_use = ++s->sched_clock;
+  return P3D_OK;
+}
+
 int check_accel(const p3d_scene* s, uint32_t accel) {
   if (accel == P3D_ACCEL_BVH && !s->has_bvh) return fail(P3D_ERR_INVALID, "accel = Bvh but the scene was created without BVH arrays");
   if (accel == P3D_ACCEL_GRID && !s->has_grid) return fail(P3D_ERR_INVALID, "accel = UGrid but the scene was created without a grid");
@@ -352,6 +425,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     if (ylast >= cam.res_y) return fail(P3D_ERR_INVALID, "tile rows outside the image");
   }
   if (cfg->integrator > P3D_PATHTRACE || cfg->sample_mode > P3D_SAMPLE_TENT) return fail(P3D_ERR_INVALID, "bad integrator / sample_mode");
+  if (cfg->tile_order > P3D_TILE_ORDER_FRAME) return fail(P3D_ERR_INVALID, "bad tile_order");
   if (cfg->max_depth < 0 || cfg->max_depth > 1024) return fail(P3D_ERR_INVALID, "max_depth out of range");
   if (cfg->antialiasing && (cfg->spp_sqrt == 0 || cfg->spp_sqrt > 1024)) return fail(P3D_ERR_INVALID, "spp_sqrt out of range");
   if (cfg->soft_shadows && !cfg->antialiasing)
@@ -401,6 +475,9 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     const uint32_t groups = (ntiles + 8 * xcd_chunk - 1) / (8 * xcd_chunk);
     return groups * 8 * xcd_chunk;
   };
+  // Cost-ordered tiles (DESIGN.md "Tile schedule"): where the frame order leaves a tail of a few
+  // long-running tiles — Whitted chains over an LDS-staged scene, more tiles than wave slots.
+  const bool sched_ok = !pt && lds_scene && cfg->tile_order == P3D_TILE_ORDER_COST && cfg->max_depth > 0;
   const uint32_t max_threads = blocks_for(tiles_x * bands_per_launch) * kBlock;
   const uint32_t levels = pt ? 0 : (uint32_t)cfg->max_depth;
   if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * max_threads * sizeof(float4)))) return rc;
@@ -428,6 +505,11 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     }
     P.tiles_x = tiles_x; P.tiles_y = nb;
     P.xcd_chunk = xcd_chunk;
+    P.sched = nullptr;
+    P.tile_cost = nullptr;
+    SchedEntry* fresh = nullptr;
+    if (sched_ok && tiles_x * nb >= kSchedMinTiles)
+      if (int rc = schedule_lookup(s, cfg, P, st, &fresh)) return rc;
     const uint32_t blocks = blocks_for(tiles_x * nb);
     P.level_stride = blocks * kBlock;
     const size_t off = (size_t)row0 * tile->w;
@@ -441,6 +523,8 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       default: e = launch_accel<P3D_ACCEL_NONE>(pt, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
     }
     if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (fresh)
+      if (int rc = schedule_finish(s, fresh, tiles_x * nb, st)) return rc;
   }
   if (stats) return finish_stats(s, st, stats);
   return P3D_OK;
@@ -519,5 +603,18 @@ int p3d_trace_closest(p3d_scene* s, uint32_t accel, uint32_t n, const float* ori
 int p3d_trace_any(p3d_scene* s, uint32_t accel, uint32_t n, const float* origin, const float* direction, uint8_t* occluded) {
   return trace_common(s, accel, n, origin, direction, nullptr, nullptr, occluded, true);
 }
+
+#ifdef P3D_TIMELINE
+int p3d_debug_set_timeline(void* device_ptr) {
+  unsigned long long* p = static_cast<unsigned long long*>(device_ptr);
+  return hipMemcpyToSymbol(HIP_SYMBOL(p3d::g_timeline), &p, sizeof(p)) == hipSuccess ? P3D_OK : P3D_ERR_NO_DEVICE;
+}
+int p3d_debug_copy_sched(p3d_scene* s, uint32_t* host_sched, size_t n_sched, uint32_t* host_cost, size_t n_cost) {
+  if (s->sched.empty()) return P3D_ERR_INVALID;
+  (void)hipDeviceSynchronize();
+  if (hipMemcpy(host_sched, s->sched[0].sched.p, n_sched * 4, hipMemcpyDeviceToHost) != hipSuccess) return P3D_ERR_NO_DEVICE;
+  return hipMemcpy(host_cost, s->sched[0].cost.p, n_cost * 4, hipMemcpyDeviceToHost) == hipSuccess ? P3D_OK : P3D_ERR_NO_DEVICE;
+}
+#endif
 
 }  // extern "C"

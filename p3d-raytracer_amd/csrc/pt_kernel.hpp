@@ -63,6 +63,8 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
   extern __shared__ float4 smem[];
   uint32_t tx, ty;
   if (!tile_of_block(P, tx, ty)) return;
+  P3D_TL_BEGIN()
+  const unsigned long long t_begin = P.tile_cost ? wall_clock64() : 0;
   DevScene sc = P.sc;
   stage_scene<LDS>(sc, P, smem);
 
@@ -275,6 +277,8 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
     }
   }
   if (STATS) flush_stats<STATS>(ct, P.stats);
+  record_tile_cost(P, tx, ty, t_begin);
+  P3D_TL_END()
 }
 
 }  // namespace p3d

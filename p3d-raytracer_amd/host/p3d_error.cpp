@@ -34,6 +34,7 @@ void p3d_config_default(p3d_config* c) {
   c->gamma = 1.0f;                 // GAMMA
   c->collect_stats = 0;
   c->skybox = 0;                   // SKYBOX is true as shipped, but the cubemap must be supplied first
+  c->tile_order = P3D_TILE_ORDER_COST;  // scheduling only
   c->seed = 0x5EED;
 }
 }

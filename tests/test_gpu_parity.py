@@ -207,6 +207,34 @@ def test_stripe_sharding_is_bit_invariant():
     assert (rgb.view(np.uint32) == full[24:57, 40:90].view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("kw,res", [(dict(), 1024), (dict(antialiasing=1, spp_sqrt=2, soft_shadows=1, depth_of_field=1), 1024),
+                                    (dict(), 2048)])
+def test_tile_order_never_changes_a_result(kw, res):
+    """p3d_config.tile_order is scheduling only: the frame-order launch, the launch that records the
+    tile costs and the launches that use the recorded schedule write the same bits (also with a
+    striped tile and with a frame that needs more than one launch)."""
+    hs = p3d.HostScene(scene_path("balls_low.p3f"))
+    hs.set_resolution(res, res)
+    dev = p3d.DeviceScene(hs, bvh=True)
+    mk = lambda order: p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, tile_order=order, **kw)
+    tiles = [None, p3d.stripe_tile((res, res), 1, 2, 8)] if res == 1024 else [None]
+    for t in tiles:
+        ref = dev.render(mk(p3d.TILE_ORDER_FRAME), tile=t, want_rgb8=True, stats=False)
+        for _ in range(3):  # 1st: frame order + cost recording, 2nd and 3rd: scheduled
+            out = dev.render(mk(p3d.TILE_ORDER_COST), tile=t, want_rgb8=True, stats=False)
+            assert (out[0].view(np.uint32) == ref[0].view(np.uint32)).all()
+            assert (out[1] == ref[1]).all() and (out[2] == ref[2]).all()
+    # the counters of a scheduled launch are those of the frame-order launch
+    a = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, tile_order=p3d.TILE_ORDER_FRAME, collect_stats=1, **kw))[2]
+    b = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, tile_order=p3d.TILE_ORDER_COST, collect_stats=1, **kw))[2]
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "node_tests", "sphere_tests", "tri_tests",
+              "shaded_hits", "pixels"):
+        assert getattr(a, k) == getattr(b, k), k
+    with pytest.raises(p3d.P3DError) as e:
+        dev.render(mk(7))
+    assert e.value.code == -1
+
+
 def test_rgb8_and_gamma():
     dev, sc = _pair(scene_path("balls_low.p3f"), res=(96, 96), grid=False)
     for gamma in (1.0, 2.2):
