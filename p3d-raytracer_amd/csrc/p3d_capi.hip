@@ -604,6 +604,12 @@ int p3d_trace_any(p3d_scene* s, uint32_t accel, uint32_t n, const float* origin,
   return trace_common(s, accel, n, origin, direction, nullptr, nullptr, occluded, true);
 }
 
+#ifdef P3D_PT_PROFILE
+int p3d_debug_set_pt_prof(void* device_ptr) {
+  unsigned long long* p = static_cast<unsigned long long*>(device_ptr);
+  return hipMemcpyToSymbol(HIP_SYMBOL(p3d::g_pt_prof), &p, sizeof(p)) == hipSuccess ? P3D_OK : P3D_ERR_NO_DEVICE;
+}
+#endif
 #ifdef P3D_TIMELINE
 int p3d_debug_set_timeline(void* device_ptr) {
   unsigned long long* p = static_cast<unsigned long long*>(device_ptr);

@@ -52,6 +52,24 @@ __device__ __forceinline__ void det_sincos(double x, double& s_out, double& c_ou
 
 constexpr float kPIf = 3.141592653589793238462f;  // camera.h:13
 
+#ifdef P3D_PT_PROFILE  // debug builds only: wave-time, entries and active lanes per region of the bounce loop
+__device__ unsigned long long* g_pt_prof = nullptr;
+constexpr int kPtRegions = 10;
+struct PtProf {
+  unsigned long long acc[kPtRegions], lanes[kPtRegions], iters[kPtRegions], last;
+  int cur;
+  __device__ void init() { for (int i = 0; i < kPtRegions; ++i) acc[i] = lanes[i] = iters[i] = 0; cur = 0; last = __builtin_readcyclecounter(); }
+  __device__ void enter(int r) {
+    const unsigned long long now = __builtin_readcyclecounter();
+    acc[cur] += now - last; last = now; cur = r;
+    lanes[r] += __popcll(__ballot(1)); iters[r] += 1;
+  }
+};
+#define PT_REGION(r) prof.enter(r);
+#else
+#define PT_REGION(r)
+#endif
+
 // pending dielectric branch (main.cpp:512-513): 3 float4 per entry, 2 entries per lane
 struct Pending {
   float4* base;  // &pend[lane]; float4 q of entry e at base[(e * 3 + q) * kBlock]
@@ -94,15 +112,21 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
 
     F3 color = f3(0, 0, 0);  // pixel accumulator (main.cpp:792)
     int first_hit = -1;
-    int s = 0;               // next sample to start
+    int s = 0;               // next sample to start, = si * SPP + sj
+    int si = 0, sj = 0;
     bool alive = false, in_sample = false, first_ray = false;
     Rng rng;
     RayS ray;
     F3 T = f3(1, 1, 1), L = f3(0, 0, 0);
     int depth = 0;
 
+#ifdef P3D_PT_PROFILE
+    PtProf prof; prof.init();
+#endif
     while (true) {
+      PT_REGION(0)
       if (!alive) {
+        PT_REGION(1)
         if (pend.n > 0) {  // resume the deferred reflection branch of a dielectric hit
           --pend.n;
           const float4 q0 = pend.base[(pend.n * 3 + 0) * kBlock], q1 = pend.base[(pend.n * 3 + 1) * kBlock],
@@ -117,7 +141,6 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
             in_sample = false;
           }
           if (s == n_samples) break;
-          const int si = s / SPP, sj = s % SPP;
           rng.seed_stream(P.seed, (uint32_t)(y * sc.cam.res_x + x), (uint32_t)s);
           st.sp = 0;
           F3 o, d;
@@ -129,14 +152,17 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
           depth = MAXD;
           first_ray = (s == 0);
           ++s;
+          if (++sj == SPP) { sj = 0; ++si; }
           alive = true;
           in_sample = true;
         }
       }
       // ---- one bounce: the body of Radiance ----
+      PT_REGION(2)
       F3 Pn;
       Geom g;
       const int obj = closest_hit<ACCEL, !LDS>(sc, st, ray, Pn, g, ct);
+      PT_REGION(3)
       if (first_ray) { first_hit = obj; first_ray = false; }
       if (obj < 0 || depth == 0) {  // main.cpp:350-355: the background acts as an environment light
         L = L + T * miss_color(P.sc, P.skybox != 0, ray.d);
@@ -163,6 +189,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
         }
       }
       if (m0.w == 1.0f) {  // ideal diffuse, main.cpp:391-480
+        PT_REGION(4)
         const float r1 = 2 * kPIf * rng.rand_float();
         const float r2 = rng.rand_float();
         const float r2s = sqrtf(r2);
@@ -197,7 +224,9 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
           ct.add(kRaysLight);
           F3 hp2;
           Geom g2;
+          PT_REGION(5)
           const int hit2 = closest_hit<ACCEL, !LDS>(sc, st, feeler, hp2, g2, ct);
+          PT_REGION(6)
           if (hit2 >= 0 && hit2 == (int)lobj) {  // main.cpp:472-475
             const double omega = (double)(2 * kPIf) * (1 - cos_a_max);
             e = e + f * (emi * dot(l, norml) * (float)omega) * (1 / kPIf);
@@ -210,6 +239,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
         continue;
       }
       if (m1.w == 1.0f) {  // mirror, main.cpp:481-484
+        PT_REGION(7)
         L = L + T * E;
         T = T * f;
         ray_set(ray, intercept_out, ray.d - norm * (2 * dot(norm, ray.d)));
@@ -217,6 +247,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
         continue;
       }
       // dielectric, main.cpp:486-515
+      PT_REGION(8)
       const F3 refl_d = ray.d - norm * 2 * dot(norm, ray.d);
       const bool into = dot(norm, norml) > 0;
       const double nc = 1.0, nt = (double)m2.z;
@@ -262,6 +293,13 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
     }
     if (P.antialiasing) color = color / (float)(SPP * SPP);  // main.cpp:800
 
+#ifdef P3D_PT_PROFILE
+    PT_REGION(9)
+    if (g_pt_prof && __ffsll((unsigned long long)__ballot(1)) - 1 == (int)lane)
+      for (int i = 0; i < kPtRegions; ++i) {
+        atomicAdd(&g_pt_prof[3 * i], prof.acc[i]); atomicAdd(&g_pt_prof[3 * i + 1], prof.lanes[i]); atomicAdd(&g_pt_prof[3 * i + 2], prof.iters[i]);
+      }
+#endif
     const size_t k = (size_t)r * P.w + c;
     if (P.rgb) {
       P.rgb[3 * k] = color.x; P.rgb[3 * k + 1] = color.y; P.rgb[3 * k + 2] = color.z;
