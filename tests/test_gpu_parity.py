@@ -207,16 +207,17 @@ def test_stripe_sharding_is_bit_invariant():
     assert (rgb.view(np.uint32) == full[24:57, 40:90].view(np.uint32)).all()
 
 
-@pytest.mark.parametrize("kw,res", [(dict(), 1024), (dict(antialiasing=1, spp_sqrt=2, soft_shadows=1, depth_of_field=1), 1024),
-                                    (dict(), 2048)])
-def test_tile_order_never_changes_a_result(kw, res):
+@pytest.mark.parametrize("kw,res,depth", [(dict(), 1024, 4),
+                                          (dict(antialiasing=1, spp_sqrt=2, soft_shadows=1, depth_of_field=1), 1024, 4),
+                                          (dict(), 2048, 250)])  # 4 KB of level records per thread: 8 launches of 8192 tiles
+def test_tile_order_never_changes_a_result(kw, res, depth):
     """p3d_config.tile_order is scheduling only: the frame-order launch, the launch that records the
     tile costs and the launches that use the recorded schedule write the same bits (also with a
     striped tile and with a frame that needs more than one launch)."""
     hs = p3d.HostScene(scene_path("balls_low.p3f"))
     hs.set_resolution(res, res)
     dev = p3d.DeviceScene(hs, bvh=True)
-    mk = lambda order: p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, tile_order=order, **kw)
+    mk = lambda order: p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=depth, tile_order=order, **kw)
     tiles = [None, p3d.stripe_tile((res, res), 1, 2, 8)] if res == 1024 else [None]
     for t in tiles:
         ref = dev.render(mk(p3d.TILE_ORDER_FRAME), tile=t, want_rgb8=True, stats=False)
@@ -225,8 +226,8 @@ def test_tile_order_never_changes_a_result(kw, res):
             assert (out[0].view(np.uint32) == ref[0].view(np.uint32)).all()
             assert (out[1] == ref[1]).all() and (out[2] == ref[2]).all()
     # the counters of a scheduled launch are those of the frame-order launch
-    a = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, tile_order=p3d.TILE_ORDER_FRAME, collect_stats=1, **kw))[2]
-    b = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, tile_order=p3d.TILE_ORDER_COST, collect_stats=1, **kw))[2]
+    a = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=depth, tile_order=p3d.TILE_ORDER_FRAME, collect_stats=1, **kw))[2]
+    b = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=depth, tile_order=p3d.TILE_ORDER_COST, collect_stats=1, **kw))[2]
     for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "node_tests", "sphere_tests", "tri_tests",
               "shaded_hits", "pixels"):
         assert getattr(a, k) == getattr(b, k), k
