@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Long differential-fuzz run (GPU kernels vs CPU oracle), outside the pytest suite.
+
+  python tests/fuzz_campaign.py [--whitted N] [--pt M] [--start S]
+
+Same generator and same bars as test_fuzz_random_scenes_* in test_gpu_parity.py, over many more
+seeds and over scene sizes on both sides of the LDS-staging limit.  Prints one line per failing
+(seed, accel) and a summary; exit code 1 if anything failed.  Test infrastructure: uses oracle/."""
+import argparse
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import p3d_amd as p3d  # noqa: E402
+from fuzz_scenes import random_scene  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+from test_gpu_parity import oracle_cfg_like  # noqa: E402
+
+COUNTERS = ("rays", "node_tests", "sphere_tests", "tri_tests", "box_tests", "plane_tests")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--whitted", type=int, default=200)
+    ap.add_argument("--pt", type=int, default=40)
+    ap.add_argument("--start", type=int, default=0)
+    a = ap.parse_args()
+    tmp = tempfile.mkdtemp()
+    fails = 0
+    worst = 0.0
+    for k in range(a.start, a.start + a.whitted):
+        size = (1, 4, 16, 60)[k % 4]  # 16 objects ... ~1000 objects (past the 16 KB LDS limit)
+        path = random_scene(50000 + k, os.path.join(tmp, "w.p3f"), n_spheres=6 * size, n_tris=8 * size, n_boxes=2 * size,
+                            n_planes=1 if k % 7 == 0 else 0, n_lights=1 + k % 4, res=(80, 64))
+        hs, sc = p3d.HostScene(path), ob.Scene(path)
+        dev = p3d.DeviceScene(hs, bvh=True, grid=True)
+        for accel in (p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH):
+            if accel == p3d.ACCEL_NONE and size > 16:
+                continue
+            kw = dict(antialiasing=1, spp_sqrt=2, soft_shadows=1, depth_of_field=k % 2, sample_disk=(k // 2) % 2,
+                      sample_mode=(k // 4) % 2, seed=k) if k % 5 == 1 else {}
+            cfg = p3d.whitted_config(accel=accel, max_depth=k % 8, collect_stats=1, **kw)
+            rgb, hit, st = dev.render(cfg)
+            o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+            m = np.isfinite(o_rgb).all(-1)
+            d = float(np.abs(rgb[m] - o_rgb[m]).max()) if m.any() else 0.0
+            worst = max(worst, d)
+            bad = []
+            if not (hit == o_hit).all(): bad.append("hit ids (%d px)" % int((hit != o_hit).sum()))
+            if not (np.isfinite(rgb).all(-1) == m).all(): bad.append("finite mask")
+            if d > 5e-6: bad.append("rgb %.3g" % d)
+            if tuple(getattr(st, c) for c in COUNTERS) != tuple(getattr(o_st, c) for c in COUNTERS): bad.append("counters")
+            if bad:
+                fails += 1
+                print("FAIL whitted seed %d accel %d size %d depth %d: %s" % (k, accel, size, k % 8, ", ".join(bad)), flush=True)
+        if k % 20 == 19:
+            print("whitted %d done, worst |rgb diff| %.3g, failures %d" % (k + 1 - a.start, worst, fails), flush=True)
+    worst_pt = 0.0
+    for k in range(a.start, a.start + a.pt):
+        size = (1, 3, 10)[k % 3]
+        path = random_scene(70000 + k, os.path.join(tmp, "p.p3f"), n_spheres=6 * size, n_tris=8 * size, n_boxes=2 * size,
+                            n_lights=0, emitters=1 + k % 3, res=(48, 48))
+        hs, sc = p3d.HostScene(path), ob.Scene(path)
+        dev = p3d.DeviceScene(hs, bvh=True, grid=True)
+        for accel in (p3d.ACCEL_GRID, p3d.ACCEL_BVH):
+            cfg = p3d.pathtrace_config(accel=accel, spp_sqrt=2 + k % 3, max_depth=6 + k % 20, dof=k % 2, seed=k, collect_stats=1,
+                                       sample_mode=(k // 2) % 2)
+            rgb, hit, st = dev.render(cfg)
+            o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+            m = np.isfinite(o_rgb).all(-1)
+            scale = max(1.0, float(np.abs(o_rgb[m]).max())) if m.any() else 1.0
+            d = float(np.abs(rgb[m] - o_rgb[m]).max()) / scale if m.any() else 0.0
+            worst_pt = max(worst_pt, d)
+            bad = []
+            if not (hit == o_hit).all(): bad.append("hit ids")
+            if not (np.isfinite(rgb).all(-1) == m).all(): bad.append("finite mask")
+            if d > 1e-4: bad.append("rgb %.3g" % d)
+            if (st.rays_primary, st.rays_bounce, st.rays_light) != (o_st.rays_primary, o_st.rays_bounce, o_st.rays_light): bad.append("ray counts")
+            if bad:
+                fails += 1
+                print("FAIL pt seed %d accel %d size %d: %s" % (k, accel, size, ", ".join(bad)), flush=True)
+        if k % 10 == 9:
+            print("pt %d done, worst relative |rgb diff| %.3g, failures %d" % (k + 1 - a.start, worst_pt, fails), flush=True)
+    print("SUMMARY whitted %d pt %d failures %d worst whitted %.3g worst pt %.3g" % (a.whitted, a.pt, fails, worst, worst_pt))
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
