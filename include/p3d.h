@@ -237,7 +237,10 @@ typedef struct p3d_stats {
   double kernel_ms;      /* HIP-event time of the kernel(s) of this call */
 } p3d_stats;
 
-typedef struct p3d_scene p3d_scene; /* device-resident scene, one per HIP device */
+/* Device-resident scene, one per HIP device.  A p3d_scene also owns per-launch scratch and the
+ * memoised tile schedules, so calls on ONE scene must not overlap in time from several host
+ * threads (as the reference's renderScene() is single-threaded); different scenes are independent. */
+typedef struct p3d_scene p3d_scene;
 
 /* ---- library ---- */
 uint32_t p3d_abi_version(void);
