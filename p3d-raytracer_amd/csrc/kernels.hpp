@@ -36,8 +36,6 @@ __device__ unsigned long long* g_timeline = nullptr;
 #define P3D_TL_END()
 #endif
 
-constexpr int kSchedClasses = 4;
-
 struct RenderParams {
   DevScene sc;
   const float4* blob;   // all float4 scene arrays, contiguous (for the LDS staging copy)
@@ -101,14 +99,7 @@ __device__ __forceinline__ bool tile_of_block(const RenderParams& P, uint32_t& t
   uint32_t tile;
   if (P.sched) {
     if (b >= n) return false;
-    uint32_t i = b;
-    int c = kSchedClasses - 1;
-    for (; c > 0; --c) {
-      const uint32_t in_class = P.sched[c];
-      if (i < in_class) break;
-      i -= in_class;
-    }
-    tile = P.sched[kSchedClasses + (uint32_t)c * n + i];
+    tile = P.sched[b];
   } else {
     const uint32_t j = b >> 3;
     tile = ((j / P.xcd_chunk) * 8 + (b & 7u)) * P.xcd_chunk + (j % P.xcd_chunk);
@@ -124,32 +115,41 @@ __device__ __forceinline__ void record_tile_cost(const RenderParams& P, uint32_t
   if (P.tile_cost && threadIdx.x == 0) P.tile_cost[ty * P.tiles_x + tx] = (uint32_t)(wall_clock64() - t_begin);
 }
 
-// One workgroup: files every tile under a cost class relative to the mean cost of the launch
-// (>= 4x, >= 2x, >= 1.25x, rest).  sched layout, n tiles: [0..4) tiles per class, then the tiles
-// of class c from kSchedClasses + c * n.
+// One workgroup: counting sort of the tiles by cost class, most expensive class first.  Classes
+// are quarter octaves of cost / mean cost, from below 1/4 to above 3.4 (order inside a class:
+// arrival).  sched[i] = the tile workgroup i renders.
 constexpr int kSchedBuildThreads = 1024;
-__host__ __device__ constexpr uint32_t sched_words(uint32_t n) { return kSchedClasses * (n + 1u); }
+constexpr int kSchedClasses = 16;
+__device__ __forceinline__ int sched_class(uint32_t cost, float mean) {
+  if (cost == 0) return 0;
+  const int c = (int)floorf(log2f((float)cost / mean) * 4.0f) + 8;
+  return c < 0 ? 0 : (c >= kSchedClasses ? kSchedClasses - 1 : c);
+}
 
 __global__ void __launch_bounds__(kSchedBuildThreads) sched_build_kernel(const uint32_t* cost, uint32_t n, uint32_t* sched) {
   __shared__ unsigned long long total;
-  __shared__ uint32_t count[kSchedClasses];
+  __shared__ uint32_t cursor[kSchedClasses];
   if (threadIdx.x == 0) total = 0;
-  if (threadIdx.x < kSchedClasses) count[threadIdx.x] = 0;
+  if (threadIdx.x < kSchedClasses) cursor[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long mine = 0;
   for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) mine += cost[t];
   for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
   if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
   __syncthreads();
-  const float mean = (float)total / (float)n;
-  for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) {
-    const float c = (float)cost[t];
-    const uint32_t cls = c >= 4.0f * mean ? 3u : (c >= 2.0f * mean ? 2u : (c >= 1.25f * mean ? 1u : 0u));
-    const uint32_t slot = atomicAdd(&count[cls], 1u);
-    sched[kSchedClasses + cls * n + slot] = t;
+  const float mean = fmaxf((float)total / (float)n, 1.0f);
+  for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) atomicAdd(&cursor[sched_class(cost[t], mean)], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {  // class sizes -> first slot of each class, most expensive class first
+    uint32_t at = 0;
+    for (int c = kSchedClasses - 1; c >= 0; --c) {
+      const uint32_t size = cursor[c];
+      cursor[c] = at;
+      at += size;
+    }
   }
   __syncthreads();
-  if (threadIdx.x < kSchedClasses) sched[threadIdx.x] = count[threadIdx.x];
+  for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) sched[atomicAdd(&cursor[sched_class(cost[t], mean)], 1u)] = t;
 }
 
 template <bool STATS>

@@ -58,14 +58,14 @@ struct Scratch {
 // given key runs in frame order and records what every tile cost, the launches after it take
 // the tiles most-expensive-class first.
 struct SchedEntry {
-  uint32_t accel = 0, aa = 0, spp = 0;
+  uint32_t accel = 0, aa = 0, spp = 0, pt = 0;
   int32_t max_depth = 0, x0 = 0, y0 = 0, w = 0, h = 0, stripe_h = 0, stripe_stride = 0;
   Scratch cost, sched;
   hipEvent_t ready = nullptr;
   hipStream_t built_on = nullptr;
   uint64_t last_use = 0;
   bool same_key(const SchedEntry& o) const {
-    return accel == o.accel && aa == o.aa && spp == o.spp && max_depth == o.max_depth && x0 == o.x0 && y0 == o.y0 &&
+    return accel == o.accel && aa == o.aa && spp == o.spp && pt == o.pt && max_depth == o.max_depth && x0 == o.x0 && y0 == o.y0 &&
            w == o.w && h == o.h && stripe_h == o.stripe_h && stripe_stride == o.stripe_stride;
   }
 };
@@ -333,10 +333,10 @@ hipError_t launch_accel(bool pt, bool aa, bool lds_scene, bool stats, const Rend
 // Looks up the schedule for the launch described by (cfg, P).  Known key: P.sched is set.  New
 // key: P.tile_cost is set so that this launch (in frame order) records the costs, and *fresh
 // points at the entry, to be completed by schedule_finish() right after the launch.
-int schedule_lookup(p3d_scene* s, const p3d_config* cfg, RenderParams& P, hipStream_t st, SchedEntry** fresh) {
+int schedule_lookup(p3d_scene* s, const p3d_config* cfg, bool pt, RenderParams& P, hipStream_t st, SchedEntry** fresh) {
   *fresh = nullptr;
   SchedEntry key;
-  key.accel = cfg->accel; key.aa = cfg->antialiasing ? 1 : 0; key.spp = cfg->antialiasing ? cfg->spp_sqrt : 1;
+  key.accel = cfg->accel; key.aa = cfg->antialiasing ? 1 : 0; key.spp = cfg->antialiasing ? cfg->spp_sqrt : 1; key.pt = pt ? 1 : 0;
   key.max_depth = P.max_depth; key.x0 = P.x0; key.y0 = P.y0; key.w = P.w; key.h = P.h;
   key.stripe_h = P.stripe_h; key.stripe_stride = P.stripe_stride;
   for (SchedEntry& c : s->sched)
@@ -358,9 +358,9 @@ int schedule_lookup(p3d_scene* s, const p3d_config* cfg, RenderParams& P, hipStr
   }
   const uint32_t n = P.tiles_x * P.tiles_y;
   if (int rc = e->cost.ensure((size_t)n * sizeof(uint32_t))) return rc;
-  if (int rc = e->sched.ensure((size_t)sched_words(n) * sizeof(uint32_t))) return rc;
+  if (int rc = e->sched.ensure((size_t)n * sizeof(uint32_t))) return rc;
   if (!e->ready) P3D_HIP(hipEventCreateWithFlags(&e->ready, hipEventDisableTiming));
-  e->accel = key.accel; e->aa = key.aa; e->spp = key.spp; e->max_depth = key.max_depth; e->x0 = key.x0; e->y0 = key.y0;
+  e->accel = key.accel; e->aa = key.aa; e->spp = key.spp; e->pt = key.pt; e->max_depth = key.max_depth; e->x0 = key.x0; e->y0 = key.y0;
   e->w = key.w; e->h = key.h; e->stripe_h = key.stripe_h; e->stripe_stride = key.stripe_stride;
   P.tile_cost = (uint32_t*)e->cost.p;
   *fresh = e;
@@ -483,7 +483,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   };
   // Cost-ordered tiles (DESIGN.md "Tile schedule"): where the frame order leaves a tail of a few
   // long-running tiles — Whitted chains over an LDS-staged scene, more tiles than wave slots.
-  const bool sched_ok = !pt && lds_scene && cfg->tile_order == P3D_TILE_ORDER_COST && cfg->max_depth > 0;
+  const bool sched_ok = lds_scene && cfg->tile_order == P3D_TILE_ORDER_COST && cfg->max_depth > 0;
   const uint32_t max_threads = blocks_for(tiles_x * bands_per_launch) * kBlock;
   const uint32_t levels = pt ? 0 : (uint32_t)cfg->max_depth;
   if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * max_threads * sizeof(float4)))) return rc;
@@ -515,7 +515,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     P.tile_cost = nullptr;
     SchedEntry* fresh = nullptr;
     if (sched_ok && tiles_x * nb >= kSchedMinTiles)
-      if (int rc = schedule_lookup(s, cfg, P, st, &fresh)) return rc;
+      if (int rc = schedule_lookup(s, cfg, pt, P, st, &fresh)) return rc;
     const uint32_t blocks = blocks_for(tiles_x * nb);
     P.level_stride = blocks * kBlock;
     const size_t off = (size_t)row0 * tile->w;
