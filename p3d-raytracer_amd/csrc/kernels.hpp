@@ -68,7 +68,7 @@ struct RenderParams {
   uint32_t* tile_cost;
 };
 
-// LDS map of one workgroup:  [ staged scene (lds_scene_f4 float4) | node stack (cap * 64 * 8 B) | pending (PT) ]
+// LDS map of one workgroup:  [ staged scene (lds_scene_f4 float4) | node stack (cap * 64 * 8 B) | per-pixel sample ring (PT, 4 lanes per pixel) ]
 template <bool LDS>
 __device__ __forceinline__ void stage_scene(DevScene& sc, const RenderParams& P, float4* smem) {
   if (LDS) {

@@ -25,6 +25,10 @@ namespace {
       return fail(P3D_ERR_NO_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+#ifndef P3D_PT_SUB4_MIN_SPP_SQRT
+#define P3D_PT_SUB4_MIN_SPP_SQRT 4
+#endif
+constexpr uint32_t kPtSub4MinSppSqrt = P3D_PT_SUB4_MIN_SPP_SQRT;  // from 16 samples per pixel: 4 lanes per pixel
 constexpr uint32_t kLdsSceneLimitBytes = 16 * 1024;  // stage the scene in LDS up to this size
 // A frame is rendered by as few launches as the per-thread scratch (level records + stack spill)
 // allows: every launch ends with a tail of partly idle CUs (2048x2048, 100k triangles: 30.3 ms in
@@ -318,16 +322,17 @@ extern "C" int p3d_scene_set_skybox(p3d_scene* s, const p3d_skybox_desc* sky) {
 namespace {
 
 template <int ACCEL, bool LDS, bool STATS>
-hipError_t launch_one(bool pt, bool aa, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
-  if (pt) hipLaunchKernelGGL((pt_kernel<ACCEL, LDS, STATS>), dim3(blocks), dim3(kBlock), lds, st, P);
+hipError_t launch_one(bool pt, bool aa, bool sub4, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+  if (pt && sub4) hipLaunchKernelGGL((pt_kernel<ACCEL, LDS, STATS, 4>), dim3(blocks), dim3(kBlock), lds, st, P);
+  else if (pt) hipLaunchKernelGGL((pt_kernel<ACCEL, LDS, STATS, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
   else if (aa) hipLaunchKernelGGL((whitted_kernel<ACCEL, LDS, STATS, true>), dim3(blocks), dim3(kBlock), lds, st, P);
   else hipLaunchKernelGGL((whitted_kernel<ACCEL, LDS, STATS, false>), dim3(blocks), dim3(kBlock), lds, st, P);
   return hipGetLastError();
 }
 template <int ACCEL>
-hipError_t launch_accel(bool pt, bool aa, bool lds_scene, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
-  if (lds_scene) return stats ? launch_one<ACCEL, true, true>(pt, aa, P, blocks, lds, st) : launch_one<ACCEL, true, false>(pt, aa, P, blocks, lds, st);
-  return stats ? launch_one<ACCEL, false, true>(pt, aa, P, blocks, lds, st) : launch_one<ACCEL, false, false>(pt, aa, P, blocks, lds, st);
+hipError_t launch_accel(bool pt, bool aa, bool sub4, bool lds_scene, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+  if (lds_scene) return stats ? launch_one<ACCEL, true, true>(pt, aa, sub4, P, blocks, lds, st) : launch_one<ACCEL, true, false>(pt, aa, sub4, P, blocks, lds, st);
+  return stats ? launch_one<ACCEL, false, true>(pt, aa, sub4, P, blocks, lds, st) : launch_one<ACCEL, false, false>(pt, aa, sub4, P, blocks, lds, st);
 }
 
 // Looks up the schedule for the launch described by (cfg, P).  Known key: P.sched is set.  New
@@ -464,17 +469,22 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   P.stats = s->d_stats;
   P.stack_cap = (int32_t)cap;
   P.lds_scene_f4 = lds_scene ? s->blob_f4 : 0;
+  // path tracer with >= 16 samples per pixel: four lanes per pixel, 4x4-pixel tiles (pt_kernel SUB = 4)
+  const bool sub4 = pt && cfg->spp_sqrt >= kPtSub4MinSppSqrt;
+  const uint32_t tp = sub4 ? 4 : 8;  // tile edge in pixels
   const size_t lds_bytes = (size_t)P.lds_scene_f4 * sizeof(float4) + (size_t)cap * kBlock * sizeof(uint2) +
-                           (pt ? (size_t)2 * 3 * kBlock * sizeof(float4) : 0);
+                           (sub4 ? sizeof(PtPixelShared) : 0);
 
   // rows per launch: whole 8-row tile bands, at most kMaxLaunchThreads threads
-  const uint32_t tiles_x = (uint32_t)(tile->w + 7) / 8;
-  const size_t scratch_per_thread = (size_t)(pt ? 0 : cfg->max_depth) * sizeof(float4) + (size_t)spill_entries * sizeof(uint2);
+  const uint32_t tiles_x = ((uint32_t)tile->w + tp - 1) / tp;
+  // per-thread global scratch: Whitted level records, or the path tracer's two deferred dielectric branches
+  const uint32_t levels = pt ? 2 * 3 : (uint32_t)cfg->max_depth;
+  const size_t scratch_per_thread = (size_t)levels * sizeof(float4) + (size_t)spill_entries * sizeof(uint2);
   const uint32_t launch_threads = (uint32_t)std::min<size_t>(kMaxLaunchThreads, kLaunchScratchBudget / std::max<size_t>(scratch_per_thread, 1));
   uint32_t bands_per_launch = std::max<uint32_t>(1, launch_threads / (tiles_x * kBlock));
-  const uint32_t total_bands = (uint32_t)(tile->h + 7) / 8;
-  if (tile->stripe_h > 0 && sh % 8 == 0 && bands_per_launch >= (uint32_t)(sh / 8))
-    bands_per_launch = (bands_per_launch / (sh / 8)) * (sh / 8);  // chunks start on a stripe boundary
+  const uint32_t total_bands = ((uint32_t)tile->h + tp - 1) / tp;
+  if (tile->stripe_h > 0 && sh % (int)tp == 0 && bands_per_launch >= (uint32_t)sh / tp)
+    bands_per_launch = (bands_per_launch / ((uint32_t)sh / tp)) * ((uint32_t)sh / tp);  // chunks start on a stripe boundary
   bands_per_launch = std::min(bands_per_launch, total_bands);
   const uint32_t xcd_chunk = lds_scene ? 1u : tiles_x;
   auto blocks_for = [&](uint32_t ntiles) {  // grid covering ntiles under the chunked XCD map
@@ -485,7 +495,6 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // long-running tiles — Whitted chains over an LDS-staged scene, more tiles than wave slots.
   const bool sched_ok = lds_scene && cfg->tile_order == P3D_TILE_ORDER_COST && cfg->max_depth > 0;
   const uint32_t max_threads = blocks_for(tiles_x * bands_per_launch) * kBlock;
-  const uint32_t levels = pt ? 0 : (uint32_t)cfg->max_depth;
   if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * max_threads * sizeof(float4)))) return rc;
   if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)spill_entries * max_threads * sizeof(uint2)))) return rc;
   P.levels = (float4*)s->levels.p;
@@ -497,14 +506,14 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   }
   for (uint32_t band0 = 0; band0 < total_bands; band0 += bands_per_launch) {
     const uint32_t nb = std::min(bands_per_launch, total_bands - band0);
-    const int row0 = (int)band0 * 8;
-    const int rows = std::min<int>((int)nb * 8, tile->h - row0);
+    const int row0 = (int)(band0 * tp);
+    const int rows = std::min<int>((int)(nb * tp), tile->h - row0);
     // a chunk starts at local row row0; stripes make the image row a function of the LOCAL
     // row of the whole tile, so pass the tile origin and offset the outputs instead
     P.x0 = tile->x0; P.w = tile->w;
     P.h = rows;
     if (P.stripe_h > 0) {
-      if (row0 % sh != 0 && nb != total_bands) return fail(P3D_ERR_UNSUPPORTED, "stripe_h must divide 8-row bands when a tile is split into several launches");
+      if (row0 % sh != 0 && nb != total_bands) return fail(P3D_ERR_UNSUPPORTED, "stripe_h must divide the tile bands when a frame is split into several launches");
       P.y0 = tile->y0 + (row0 / sh) * sh * ss + (row0 % sh);
     } else {
       P.y0 = tile->y0 + row0;
@@ -524,9 +533,9 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     P.rgb8 = d_rgb8 ? d_rgb8 + 3 * off : nullptr;
     hipError_t e;
     switch (cfg->accel) {
-      case P3D_ACCEL_BVH: e = launch_accel<P3D_ACCEL_BVH>(pt, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
-      case P3D_ACCEL_GRID: e = launch_accel<P3D_ACCEL_GRID>(pt, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
-      default: e = launch_accel<P3D_ACCEL_NONE>(pt, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+      case P3D_ACCEL_BVH: e = launch_accel<P3D_ACCEL_BVH>(pt, cfg->antialiasing != 0, sub4, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+      case P3D_ACCEL_GRID: e = launch_accel<P3D_ACCEL_GRID>(pt, cfg->antialiasing != 0, sub4, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+      default: e = launch_accel<P3D_ACCEL_NONE>(pt, cfg->antialiasing != 0, sub4, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
     }
     if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
     if (fresh)

@@ -70,13 +70,34 @@ struct PtProf {
 #define PT_REGION(r)
 #endif
 
-// pending dielectric branch (main.cpp:512-513): 3 float4 per entry, 2 entries per lane
+// pending dielectric branch (main.cpp:512-513): 3 float4 per entry, 2 entries per lane, in the
+// global scratch the Whitted kernel uses for its level records (rarely touched: only the first
+// two bounces on glass fork; 6 KB of LDS per wave would cost the path tracer a wave per SIMD)
 struct Pending {
-  float4* base;  // &pend[lane]; float4 q of entry e at base[(e * 3 + q) * kBlock]
+  float4* base;     // &scratch[thread]; float4 q of entry e at base[(e * 3 + q) * stride]
+  uint32_t stride;  // threads of the launch
   int n;
 };
 
-template <int ACCEL, bool LDS, bool STATS>
+// SUB = 4: four lanes per pixel (a wave renders a 4x4-pixel tile).  The samples of a pixel are
+// independent (own RNG stream each) but main.cpp:792-800 adds them up in sample order, and float
+// addition does not commute: the four lanes take the pixel's samples in order from a shared
+// counter, post each finished sample's radiance to a small ring in LDS, and lane 0 of the pixel
+// adds the ring entries to the pixel colour strictly in sample order.  Same samples, same sum,
+// four times more and four times shorter workgroups (DESIGN.md "Tile schedule": the path
+// tracer's frame ends with a tail as long as its last tiles).
+constexpr int kPtRing = 16;  // finished samples a pixel can hold before the oldest one is added
+struct PtPixelShared {       // [..][pixel]: the 16 pixels of the tile are the fastest index (LDS banks)
+  uint32_t next_start[16];   // next sample index to hand out (runs past the last sample: one ticket per finished lane)
+  uint32_t next_add[16];     // next sample index to add to the pixel colour
+  int32_t first_hit[16];
+  uint32_t tag[kPtRing][16];       // sample index + 1 of the radiance in that ring slot
+  float radiance[kPtRing][3][16];
+};
+
+typedef __attribute__((address_space(3))) volatile PtPixelShared LdsPtPixelShared;
+
+template <int ACCEL, bool LDS, bool STATS, int SUB = 1>
 __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderParams P) {
   extern __shared__ float4 smem[];
   uint32_t tx, ty;
@@ -87,7 +108,10 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
   stage_scene<LDS>(sc, P, smem);
 
   const uint32_t lane = threadIdx.x;
-  const int c = (int)(tx * 8 + (lane & 7)), r = (int)(ty * 8 + (lane >> 3));
+  constexpr int TP = SUB == 4 ? 4 : 8;                       // tile edge in pixels
+  const uint32_t px = SUB == 4 ? lane >> 2 : lane;           // pixel of the tile this lane works for
+  const uint32_t sub = SUB == 4 ? lane & 3u : 0u;
+  const int c = (int)(tx * TP + (px % TP)), r = (int)(ty * TP + (px / TP));
   Counters<STATS> ct;
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
@@ -97,8 +121,18 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
   st.sp = 0;
   st.cap = P.stack_cap;
   Pending pend;
-  pend.base = smem + P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2 + lane;  // after the node stack
+  pend.base = P.levels + (blockIdx.x * kBlock + lane);
+  pend.stride = P.level_stride;
   pend.n = 0;
+  // after the node stack (only allocated for SUB == 4); explicit LDS address space: a generic
+  // pointer would compile to flat_load/flat_store, which are not ordered with the ds_* traffic
+  LdsPtPixelShared& shared = *(LdsPtPixelShared*)(smem + P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2);
+  if (SUB == 4 && sub == 0) {
+    shared.next_start[px] = 0;
+    shared.next_add[px] = 0;
+    shared.first_hit[px] = -1;
+    for (int k = 0; k < kPtRing; ++k) shared.tag[k][px] = 0;
+  }
 
   const bool active = c < P.w && r < P.h;
   if (active) {
@@ -108,11 +142,11 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
     const int SPP = (int)P.spp_sqrt;
     const int n_samples = SPP * SPP;
     const int MAXD = P.max_depth;
-    ct.add(kPixels);
+    if (sub == 0) ct.add(kPixels);
 
     F3 color = f3(0, 0, 0);  // pixel accumulator (main.cpp:792)
     int first_hit = -1;
-    int s = 0;               // next sample to start, = si * SPP + sj
+    int s = 0;               // SUB == 1: next sample to start; SUB == 4: the sample this lane is tracing
     int si = 0, sj = 0;
     bool alive = false, in_sample = false, first_ray = false;
     Rng rng;
@@ -123,24 +157,75 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
 #ifdef P3D_PT_PROFILE
     PtProf prof; prof.init();
 #endif
+    // SUB == 4 lets lanes of one wave wait for each other (a full ring, lane 0 waiting for the last
+    // samples of its pixel).  A waiting lane must never spin on its own: the loop is therefore
+    // wave-uniform — its exit test is a ballot every lane of the wave takes part in, once per trip —
+    // and a waiting lane simply sits out the rest of the trip.  (With a per-lane `continue` as the
+    // only way round, LLVM split the wait cycle off as an inner loop for the brute-force and grid
+    // instantiations and the waiting lanes starved the working ones.)  The trip bound is a backstop:
+    // no lane can need more trips than the pixel's whole sample set traced by one lane.
+    unsigned long long trips_left = (unsigned long long)n_samples * (unsigned)(MAXD + 2) * 4ull + 1024ull;
+    bool done = false, holding = false;
+    const uint32_t spp_magic = (uint32_t)((0x100000000ull + (unsigned)SPP - 1) / (unsigned)SPP);
     while (true) {
+      if (SUB == 4) {
+        if (trips_left-- == 0) done = true;
+        if (__ballot(!done) == 0) break;
+        if (done) continue;
+      }
       PT_REGION(0)
+      // lane 0 of a pixel adds its finished samples to the pixel colour, strictly in sample order:
+      // whenever it is between two of its own samples, and every fourth trip while it traces one
+      if (SUB == 4 && sub == 0 && (!alive || (trips_left & 3) == 0)) {
+        uint32_t na = shared.next_add[px];
+        const uint32_t before = na;
+        while (na < (uint32_t)n_samples && shared.tag[na % kPtRing][px] == na + 1) {
+          const int k = (int)(na % kPtRing);
+          color = color + f3(shared.radiance[k][0][px], shared.radiance[k][1][px], shared.radiance[k][2][px]);
+          ++na;
+        }
+        if (na != before) shared.next_add[px] = na;
+      }
       if (!alive) {
         PT_REGION(1)
         if (pend.n > 0) {  // resume the deferred reflection branch of a dielectric hit
           --pend.n;
-          const float4 q0 = pend.base[(pend.n * 3 + 0) * kBlock], q1 = pend.base[(pend.n * 3 + 1) * kBlock],
-                       q2 = pend.base[(pend.n * 3 + 2) * kBlock];
+          const float4 q0 = pend.base[(size_t)(pend.n * 3 + 0) * pend.stride], q1 = pend.base[(size_t)(pend.n * 3 + 1) * pend.stride],
+                       q2 = pend.base[(size_t)(pend.n * 3 + 2) * pend.stride];
           ray_set(ray, f3(q0.x, q0.y, q0.z), f3(q0.w, q1.x, q1.y));
           T = f3(q1.z, q1.w, q2.x);
           depth = __float_as_int(q2.y);
           alive = true;
         } else {
           if (in_sample) {
-            color = color + L;
+            if (SUB == 4) {  // post the finished sample; its ring slot is free (guaranteed when it was handed out)
+              const int k = s % kPtRing;
+              shared.radiance[k][0][px] = L.x; shared.radiance[k][1][px] = L.y; shared.radiance[k][2][px] = L.z;
+              shared.tag[k][px] = (uint32_t)s + 1;
+            } else {
+              color = color + L;
+            }
             in_sample = false;
           }
-          if (s == n_samples) break;
+          if (SUB == 4) {
+            // Take the pixel's next sample (one LDS atomic hands simultaneous takers distinct
+            // tickets), then hold it until the ring has room for its radiance: the oldest sample
+            // still being traced blocks the adder, and with it the slot kPtRing samples ahead.
+            if (!holding) {
+              s = (int)__hip_atomic_fetch_add(&shared.next_start[px], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              holding = true;
+            }
+            if (s >= n_samples) {  // nothing left to start: finished, except lane 0 while samples remain to be added
+              done = sub != 0 || shared.next_add[px] >= (uint32_t)n_samples;
+              continue;
+            }
+            if ((uint32_t)s >= shared.next_add[px] + kPtRing) continue;  // wait for room
+            holding = false;
+            si = (int)__umulhi((uint32_t)s, spp_magic);  // s / SPP (exact: s * SPP < 2^32)
+            sj = s - si * SPP;
+          } else if (s == n_samples) {
+            break;
+          }
           rng.seed_stream(P.seed, (uint32_t)(y * sc.cam.res_x + x), (uint32_t)s);
           st.sp = 0;
           F3 o, d;
@@ -151,8 +236,10 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
           L = f3(0, 0, 0);
           depth = MAXD;
           first_ray = (s == 0);
-          ++s;
-          if (++sj == SPP) { sj = 0; ++si; }
+          if (SUB == 1) {
+            ++s;
+            if (++sj == SPP) { sj = 0; ++si; }
+          }
           alive = true;
           in_sample = true;
         }
@@ -163,7 +250,11 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
       Geom g;
       const int obj = closest_hit<ACCEL, !LDS>(sc, st, ray, Pn, g, ct);
       PT_REGION(3)
-      if (first_ray) { first_hit = obj; first_ray = false; }
+      if (first_ray) {
+        first_hit = obj;
+        if (SUB == 4) shared.first_hit[px] = obj;
+        first_ray = false;
+      }
       if (obj < 0 || depth == 0) {  // main.cpp:350-355: the background acts as an environment light
         L = L + T * miss_color(P.sc, P.skybox != 0, ray.d);
         alive = false;
@@ -281,9 +372,9 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
       } else {  // first two bounces trace both; g++ evaluates the transmission operand first
         {  // at most two levels fork (depth > MAX_DEPTH-2), so two pending entries suffice
           const F3 Tr_ = T * (float)Re;
-          pend.base[(pend.n * 3 + 0) * kBlock] = make_float4(intercept_out.x, intercept_out.y, intercept_out.z, refl_d.x);
-          pend.base[(pend.n * 3 + 1) * kBlock] = make_float4(refl_d.y, refl_d.z, Tr_.x, Tr_.y);
-          pend.base[(pend.n * 3 + 2) * kBlock] = make_float4(Tr_.z, __int_as_float(depth), 0, 0);
+          pend.base[(size_t)(pend.n * 3 + 0) * pend.stride] = make_float4(intercept_out.x, intercept_out.y, intercept_out.z, refl_d.x);
+          pend.base[(size_t)(pend.n * 3 + 1) * pend.stride] = make_float4(refl_d.y, refl_d.z, Tr_.x, Tr_.y);
+          pend.base[(size_t)(pend.n * 3 + 2) * pend.stride] = make_float4(Tr_.z, __int_as_float(depth), 0, 0);
           ++pend.n;
         }
         T = T * (float)Tr;
@@ -300,18 +391,21 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
         atomicAdd(&g_pt_prof[3 * i], prof.acc[i]); atomicAdd(&g_pt_prof[3 * i + 1], prof.lanes[i]); atomicAdd(&g_pt_prof[3 * i + 2], prof.iters[i]);
       }
 #endif
-    const size_t k = (size_t)r * P.w + c;
-    if (P.rgb) {
-      P.rgb[3 * k] = color.x; P.rgb[3 * k + 1] = color.y; P.rgb[3 * k + 2] = color.z;
-    }
-    if (P.hit_id) P.hit_id[k] = first_hit;
-    if (P.rgb8) {
-      F3 gc = color;
-      if (P.gamma != 1.0f) {
-        const double ig = (double)(1 / P.gamma);
-        gc = f3((float)pow((double)color.x, ig), (float)pow((double)color.y, ig), (float)pow((double)color.z, ig));
+    if (sub == 0) {  // SUB == 4: lane 0 of the pixel holds its colour
+      if (SUB == 4) first_hit = shared.first_hit[px];
+      const size_t k = (size_t)r * P.w + c;
+      if (P.rgb) {
+        P.rgb[3 * k] = color.x; P.rgb[3 * k + 1] = color.y; P.rgb[3 * k + 2] = color.z;
       }
-      P.rgb8[3 * k] = u8fromfloat(gc.x); P.rgb8[3 * k + 1] = u8fromfloat(gc.y); P.rgb8[3 * k + 2] = u8fromfloat(gc.z);
+      if (P.hit_id) P.hit_id[k] = first_hit;
+      if (P.rgb8) {
+        F3 gc = color;
+        if (P.gamma != 1.0f) {
+          const double ig = (double)(1 / P.gamma);
+          gc = f3((float)pow((double)color.x, ig), (float)pow((double)color.y, ig), (float)pow((double)color.z, ig));
+        }
+        P.rgb8[3 * k] = u8fromfloat(gc.x); P.rgb8[3 * k + 1] = u8fromfloat(gc.y); P.rgb8[3 * k + 2] = u8fromfloat(gc.z);
+      }
     }
   }
   if (STATS) flush_stats<STATS>(ct, P.stats);

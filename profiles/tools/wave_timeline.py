@@ -29,7 +29,7 @@ if kind == "pt":
     cfg = p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=arg, tile_order=tile_order)
 else:
     cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=arg, tile_order=tile_order)
-nblk = ((res + 7) // 8) ** 2
+nblk = ((res + 3) // 4) ** 2 if kind == "pt" else ((res + 7) // 8) ** 2  # upper bound (the path tracer uses 4x4-pixel tiles from 16 spp)
 tl = torch.zeros(3 * (nblk + 64), dtype=torch.int64, device="cuda")
 if not hasattr(dev._L, "p3d_debug_set_timeline"):
     sys.exit("P3D_LIB must point at build/variants/libp3d_timeline.so (make -C p3d-raytracer_amd debuglibs)")

@@ -205,6 +205,22 @@ def test_stripe_sharding_is_bit_invariant():
     t = p3d.Tile(40, 24, 50, 33, 0, 1)
     rgb, hit, _ = dev.render(cfg, tile=t)
     assert (rgb.view(np.uint32) == full[24:57, 40:90].view(np.uint32)).all()
+    # path tracer: 8x8 tiles with one lane per pixel (9 spp) and 4x4 tiles with four lanes per pixel (16 spp)
+    dev, _ = _pair(scene_path("path_glass.p3f"), res=(64, 64), grid=False)
+    for spp_sqrt in (3, 4):
+        cfg = p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=spp_sqrt, max_depth=12, seed=7)
+        full, full_hit, _ = dev.render(cfg)
+        for world, sh in ((2, 8), (4, 4), (2, 16)):
+            out = np.zeros_like(full)
+            out_hit = np.zeros_like(full_hit)
+            for rank in range(world):
+                rgb, hit, _ = dev.render(cfg, tile=p3d.stripe_tile((64, 64), rank, world, sh))
+                rows = p3d.stripe_rows((64, 64), rank, world, sh)
+                out[rows] = rgb
+                out_hit[rows] = hit
+            assert (out.view(np.uint32) == full.view(np.uint32)).all() and (out_hit == full_hit).all()
+        rgb, hit, _ = dev.render(cfg, tile=p3d.Tile(10, 6, 37, 29, 0, 1))
+        assert (rgb.view(np.uint32) == full[6:35, 10:47].view(np.uint32)).all()
 
 
 @pytest.mark.parametrize("kw,res,depth", [(dict(), 1024, 4),
