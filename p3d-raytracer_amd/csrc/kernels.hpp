@@ -36,6 +36,30 @@ __device__ unsigned long long* g_timeline = nullptr;
 #define P3D_TL_END()
 #endif
 
+#ifdef P3D_PT_PROFILE  // debug builds only: wave-time, entries and active lanes per region of a kernel's loop
+__device__ unsigned long long* g_pt_prof = nullptr;
+constexpr int kProfRegions = 12;
+struct RegionProf {
+  unsigned long long acc[kProfRegions], lanes[kProfRegions], iters[kProfRegions], last;
+  int cur;
+  __device__ void init() { for (int i = 0; i < kProfRegions; ++i) acc[i] = lanes[i] = iters[i] = 0; cur = 0; last = __builtin_readcyclecounter(); }
+  __device__ void enter(int r) {
+    const unsigned long long now = __builtin_readcyclecounter();
+    acc[cur] += now - last; last = now; cur = r;
+    lanes[r] += __popcll(__ballot(1)); iters[r] += 1;
+  }
+  __device__ void flush() {
+    if (g_pt_prof && __ffsll((unsigned long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63))
+      for (int i = 0; i < kProfRegions; ++i) {
+        atomicAdd(&g_pt_prof[3 * i], acc[i]); atomicAdd(&g_pt_prof[3 * i + 1], lanes[i]); atomicAdd(&g_pt_prof[3 * i + 2], iters[i]);
+      }
+  }
+};
+#define PT_REGION(r) prof.enter(r);
+#else
+#define PT_REGION(r)
+#endif
+
 struct RenderParams {
   DevScene sc;
   const float4* blob;   // all float4 scene arrays, contiguous (for the LDS staging copy)
@@ -248,6 +272,9 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
     int first_hit = -1;
     Rng rng;
     rng.state = 0; rng.inc = 1;
+#ifdef P3D_PT_PROFILE
+    RegionProf prof; prof.init();
+#endif
     for (int si = 0; si < SPP; ++si) {
       for (int sj = 0; sj < SPP; ++sj) {
         if (AA) rng.seed_stream(P.seed, (uint32_t)(y * sc.cam.res_x + x), (uint32_t)(si * SPP + sj));
@@ -264,9 +291,11 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
         int level = 0;
         F3 result;
         while (true) {  // the reflect / refract chain of main.cpp:92-309 (a chain, not a tree: Q3)
+          PT_REGION(1)
           F3 Pn;
           Geom g;
           const int obj = closest_hit<ACCEL, !LDS>(sc, st, ray, Pn, g, ct);
+          PT_REGION(2)
           if (level == 0 && si == 0 && sj == 0) first_hit = obj;
           if (obj < 0) {  // main.cpp:144-147
             result = miss_color(P.sc, P.skybox != 0, ray.d);
@@ -287,11 +316,14 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
                 const float jx = rng.rand_float();
                 lpos = f3(l0.x + P.light_side * (si + jx) / SPP, l0.y + P.light_side * (sj + jy) / SPP, l0.z);
               }
+              PT_REGION(3)
               const F3 l_dir = normalized(lpos - intercept);
               RayS feeler;
               ray_set(feeler, intercept, l_dir);
               ct.add(kRaysShadow);
+              PT_REGION(4)
               const bool shadowed = any_hit<ACCEL, !LDS>(sc, st, feeler, ct);
+              PT_REGION(5)
               const F3 blinn = normalized((l_dir + get_direction(ray) * -1.0f) / 2);
               if (!shadowed) {  // main.cpp:222-225: max() and pow() evaluate in double
                 const float4 l1 = P.sc.lights[2 * li + 1];
@@ -306,6 +338,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
               }
             }
           }
+          PT_REGION(6)
           const float4 m2 = sc.mats[4 * m + 2];
           const float mKd = sc.mats[4 * m].w, mKs = sc.mats[4 * m + 1].w;
           const F3 col = diff * mKd + spec * mKs;  // main.cpp:232
@@ -359,6 +392,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
           ior_1 = child_ior;
           inside = child_inside;
         }
+        PT_REGION(7)
         // fold the chain bottom-up with the per-level clamp (main.cpp:305-307, Q4)
         while (level > 0) {
           --level;
@@ -369,6 +403,10 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
       }
     }
     if (AA) color = color / (float)(SPP * SPP);  // main.cpp:800
+#ifdef P3D_PT_PROFILE
+    PT_REGION(8)
+    prof.flush();
+#endif
 
     const size_t k = (size_t)r * P.w + c;
     if (P.rgb) {

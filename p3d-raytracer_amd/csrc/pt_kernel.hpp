@@ -52,24 +52,6 @@ __device__ __forceinline__ void det_sincos(double x, double& s_out, double& c_ou
 
 constexpr float kPIf = 3.141592653589793238462f;  // camera.h:13
 
-#ifdef P3D_PT_PROFILE  // debug builds only: wave-time, entries and active lanes per region of the bounce loop
-__device__ unsigned long long* g_pt_prof = nullptr;
-constexpr int kPtRegions = 10;
-struct PtProf {
-  unsigned long long acc[kPtRegions], lanes[kPtRegions], iters[kPtRegions], last;
-  int cur;
-  __device__ void init() { for (int i = 0; i < kPtRegions; ++i) acc[i] = lanes[i] = iters[i] = 0; cur = 0; last = __builtin_readcyclecounter(); }
-  __device__ void enter(int r) {
-    const unsigned long long now = __builtin_readcyclecounter();
-    acc[cur] += now - last; last = now; cur = r;
-    lanes[r] += __popcll(__ballot(1)); iters[r] += 1;
-  }
-};
-#define PT_REGION(r) prof.enter(r);
-#else
-#define PT_REGION(r)
-#endif
-
 // pending dielectric branch (main.cpp:512-513): 3 float4 per entry, 2 entries per lane, in the
 // global scratch the Whitted kernel uses for its level records (rarely touched: only the first
 // two bounces on glass fork; 6 KB of LDS per wave would cost the path tracer a wave per SIMD)
@@ -155,7 +137,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
     int depth = 0;
 
 #ifdef P3D_PT_PROFILE
-    PtProf prof; prof.init();
+    RegionProf prof; prof.init();
 #endif
     // SUB == 4 lets lanes of one wave wait for each other (a full ring, lane 0 waiting for the last
     // samples of its pixel).  A waiting lane must never spin on its own: the loop is therefore
@@ -386,10 +368,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
 
 #ifdef P3D_PT_PROFILE
     PT_REGION(9)
-    if (g_pt_prof && __ffsll((unsigned long long)__ballot(1)) - 1 == (int)lane)
-      for (int i = 0; i < kPtRegions; ++i) {
-        atomicAdd(&g_pt_prof[3 * i], prof.acc[i]); atomicAdd(&g_pt_prof[3 * i + 1], prof.lanes[i]); atomicAdd(&g_pt_prof[3 * i + 2], prof.iters[i]);
-      }
+    prof.flush();
 #endif
     if (sub == 0) {  // SUB == 4: lane 0 of the pixel holds its colour
       if (SUB == 4) first_hit = shared.first_hit[px];
