@@ -44,6 +44,7 @@ struct RegionProf {
   int cur;
   __device__ void init() { for (int i = 0; i < kProfRegions; ++i) acc[i] = lanes[i] = iters[i] = 0; cur = 0; last = __builtin_readcyclecounter(); }
   __device__ void enter(int r) {
+    __builtin_amdgcn_s_waitcnt(0);  // outstanding loads belong to the region that issued them
     const unsigned long long now = __builtin_readcyclecounter();
     acc[cur] += now - last; last = now; cur = r;
     lanes[r] += __popcll(__ballot(1)); iters[r] += 1;
@@ -301,11 +302,13 @@ __global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(cons
             result = miss_color(P.sc, P.skybox != 0, ray.d);
             break;
           }
+          PT_REGION(9)
           ct.add(kShadedHits);
           const uint32_t m = geom_material(g);  // material rows are re-read where used, not carried
           const F3 intercept = offset_intersection(Pn, get_normal(g, sc.normals, Pn));  // main.cpp:165
           F3 norm = get_normal(g, sc.normals, intercept);                               // main.cpp:167
           F3 diff = f3(0, 0, 0), spec = f3(0, 0, 0);
+          PT_REGION(10)
           if (!inside) {  // main.cpp:172-227
             for (uint32_t li = 0; li < sc.n_lights; ++li) {
               // the light index is wave-uniform: read through the scalar cache (s_load), not LDS

@@ -4,7 +4,9 @@
   make -C p3d-raytracer_amd debuglibs
   P3D_LIB=$PWD/build/variants/libp3d_ptprof.so python profiles/tools/whitted_regions.py tests/golden/scenes/balls_low.p3f 1024 4
 
-s_memtime deltas, entries and active lanes per region of whitted_kernel's chain loop, summed over all waves."""
+s_memtime deltas, entries and active lanes per region of whitted_kernel's chain loop, summed over all waves.
+The mark behind the closest-hit query is taken by the first lanes that leave the traversal loop, so
+the second line is the time they then wait for the slowest lane of the wave (divergence)."""
 import ctypes as C
 import os
 import sys
@@ -38,8 +40,9 @@ for _ in range(2):
     dev.render_device(cfg, tile, rgb.data_ptr())
     torch.cuda.synchronize()
 p = prof.cpu().numpy().reshape(12, 3).astype(np.float64)
-names = ["prologue: staging, primary ray", "closest hit", "hit: miss colour / normal, offset point", "light: direction, feeler set-up",
-         "any hit (shadow feeler)", "light: Blinn-Phong, pow", "child ray (reflect / refract), level record", "fold (reads the level records back)", "output"]
+names = ["prologue: staging, primary ray", "closest hit", "closest hit: lanes done, waiting for the slowest", "light: direction, feeler set-up",
+         "any hit (shadow feeler)", "light: Blinn-Phong, pow", "child ray (reflect / refract), level record", "fold (reads the level records back)", "output",
+         "hit: normal, offset point", "before the light loop", ""]
 print("%-44s %8s %10s %9s" % ("region", "time %", "entries", "lanes/64"))
 for i, n in enumerate(names):
     if p[i, 2] > 0 or p[i, 0] > 0:
