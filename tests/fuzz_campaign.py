@@ -67,7 +67,7 @@ def main():
         hs, sc = p3d.HostScene(path), ob.Scene(path)
         dev = p3d.DeviceScene(hs, bvh=True, grid=True)
         for accel in (p3d.ACCEL_GRID, p3d.ACCEL_BVH):
-            cfg = p3d.pathtrace_config(accel=accel, spp_sqrt=2 + k % 3, max_depth=6 + k % 20, dof=k % 2, seed=k, collect_stats=1,
+            cfg = p3d.pathtrace_config(accel=accel, spp_sqrt=2 + k % 6, max_depth=6 + k % 20, dof=k % 2, seed=k, collect_stats=1,
                                        sample_mode=(k // 2) % 2)
             rgb, hit, st = dev.render(cfg)
             o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
