@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production).  gloo stages the gather through host memory: only for "
                          "rehearsing the N>1 code path with several ranks on ONE GPU")
+    ap.add_argument("--gather-batch", type=int, default=8,
+                    help="N > 1: frames rendered back to back into one buffer per collective (every frame still reaches "
+                         "rank 0; a 0.15 ms frame cannot pay for a collective launch of its own)")
     ap.add_argument("--gather", default="u8", choices=["u8", "f32"],
                     help="N>1: what rank 0 collects per frame: the u8 image (img_Data, 3 B/px) or float RGB + hit IDs (16 B/px)")
     return ap.parse_args()
@@ -117,64 +120,84 @@ def main():
     stream = torch.cuda.current_stream()
 
     # Every rank renders ALL outputs of its stripes into HBM: float RGB + hit IDs (one packed
-    # allocation, 16 B/px) and the gamma-corrected u8 image (img_Data, 3 B/px).  Rank 0 collects
-    # one of the two per frame with a single collective (--gather).
+    # allocation, 16 B/px) and the gamma-corrected u8 image (img_Data, 3 B/px).  Rank 0 collects one
+    # of the two (--gather) for EVERY frame; B = --gather-batch consecutive frames share one
+    # collective (their buffers are adjacent), double-buffered against the rendering of the next B.
+    B = max(1, args.gather_batch) if world > 1 else 1
+    packed_sz, u8_sz = p3d.packed_bytes(n_local), n_local * 3
+
     def new_bufs():
-        return (torch.empty(p3d.packed_bytes(n_local), dtype=torch.uint8, device="cuda"),
-                torch.empty(n_local * 3, dtype=torch.uint8, device="cuda"))
+        return (torch.empty(B * packed_sz, dtype=torch.uint8, device="cuda"), torch.empty(B * u8_sz, dtype=torch.uint8, device="cuda"))
     bufs = [new_bufs(), new_bufs()]
     handles = [None, None]
+    filled = [0, 0]       # frames rendered into each batch buffer since its last gather
+    in_flight = [0, 0]    # frames of the batch a pending gather carries
+    sent_seq = [0, 0]     # order in which the slots' collectives were launched
+    last_frame = [None]   # (slot, index) of the newest frame assembled on rank 0
     pick = (lambda pair: pair[1]) if args.gather == "u8" else (lambda pair: pair[0])
     gdev = "cpu" if host_staged else "cuda"
     # (every rank keeps receive buffers: only rank 0 uses them unless the backend forces all_gather)
     gathered = ([[torch.empty(pick(bufs[0]).shape, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
                 if world > 1 else None)
-    frame8 = torch.empty((res, res, 3), dtype=torch.uint8, device=gdev) if rank == 0 and world > 1 else None
-    frame_rgb = torch.empty((res, res, 3), dtype=torch.float32, device=gdev) if rank == 0 and world > 1 else None
-    frame_hit = torch.empty((res, res), dtype=torch.int32, device=gdev) if rank == 0 and world > 1 else None
+    frame8 = torch.empty((B, res, res, 3), dtype=torch.uint8, device=gdev) if rank == 0 and world > 1 else None
+    frame_rgb = torch.empty((B, res, res, 3), dtype=torch.float32, device=gdev) if rank == 0 and world > 1 else None
+    frame_hit = torch.empty((B, res, res), dtype=torch.int32, device=gdev) if rank == 0 and world > 1 else None
 
     def assemble(slot):
         if args.gather == "u8":
-            p3d.assemble_frame8(gathered[slot], (res, res), world, stripe_h, frame8)
+            p3d.assemble_frame8(gathered[slot], (res, res), world, stripe_h, frame8, batch=B)
         else:
-            p3d.assemble_frame(gathered[slot], (res, res), world, stripe_h, frame_rgb, frame_hit)
+            p3d.assemble_frame(gathered[slot], (res, res), world, stripe_h, frame_rgb, frame_hit, batch=B)
+        last_frame[0] = in_flight[slot] - 1
 
     ev_pairs = []
 
-    def render_into(pair, tile_, cfg_, stats=None):
+    def render_into(pair, tile_, cfg_, stats=None, frame=0):
         packed, u8 = pair
-        dev.render_device(cfg_, tile_, d_rgb=packed.data_ptr(), d_hit=packed.data_ptr() + (tile_.w * tile_.h) * 12,
-                          d_rgb8=u8.data_ptr(), stream=stream.cuda_stream, stats=stats)
+        n_px = tile_.w * tile_.h
+        base = packed.data_ptr() + frame * p3d.packed_bytes(n_px)
+        dev.render_device(cfg_, tile_, d_rgb=base, d_hit=base + n_px * 12, d_rgb8=u8.data_ptr() + frame * n_px * 3,
+                          stream=stream.cuda_stream, stats=stats)
 
-    def step(i, timed):
-        slot = i & 1
+    def finish(slot):  # the collective of this slot has to be complete before the buffer is reused
         if handles[slot] is not None:
             handles[slot].wait()
             if rank == 0:
                 assemble(slot)
             handles[slot] = None
+
+    def send(slot):
+        if world > 1 and filled[slot]:
+            payload = pick(bufs[slot]).cpu() if host_staged else pick(bufs[slot])
+            handles[slot], _ = p3d.gather_frame(payload, (res, res), rank, world, stripe_h, 0, gathered[slot], async_op=True)
+            in_flight[slot], filled[slot] = filled[slot], 0
+            sent_seq[slot] = max(sent_seq) + 1
+
+    def step(i, timed):
+        slot, f = (i // B) & 1, i % B
+        if f == 0:
+            finish(slot)
         # kernel duration for the roofline: HIP events on the launch stream around every 8th timed
         # step (an event pair costs a few microseconds of stream time, comparable to 3 % of this frame)
         probe = timed and (i % 8 == 0)
         if probe:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-        render_into(bufs[slot], tile, cfg)
+        render_into(bufs[slot], tile, cfg, frame=f)
         if probe:
             e1.record(stream)
             ev_pairs.append((e0, e1))
-        if world > 1:
-            payload = pick(bufs[slot]).cpu() if host_staged else pick(bufs[slot])
-            handles[slot], _ = p3d.gather_frame(payload, (res, res), rank, world, stripe_h, 0, gathered[slot],
-                                                async_op=True)
+        filled[slot] += 1
+        if f == B - 1:
+            send(slot)
 
-    def drain():
+    def drain():  # a partly filled batch goes out as it is; then every collective is completed, oldest first
         for slot in (0, 1):
-            if handles[slot] is not None:
-                handles[slot].wait()
-                if rank == 0:
-                    assemble(slot)
-                handles[slot] = None
+            if filled[slot]:
+                finish(slot)
+                send(slot)
+        for slot in sorted((0, 1), key=lambda k: sent_seq[k]):
+            finish(slot)
 
     def barrier():
         torch.cuda.synchronize()
@@ -217,11 +240,12 @@ def main():
         render_into(ref_pair, full, cfg)
         torch.cuda.synchronize()
         ref_packed, ref_u8 = ref_pair[0].to(gdev), ref_pair[1].to(gdev)
+        k = last_frame[0]
         if args.gather == "u8":
-            ok = bool(torch.equal(frame8.view(-1), ref_u8))
+            ok = bool(torch.equal(frame8[k].reshape(-1), ref_u8))
         else:
-            ok = bool(torch.equal(frame_rgb.view(-1).view(torch.int32), ref_packed[: res * res * 12].view(torch.int32))
-                      and torch.equal(frame_hit.view(-1), ref_packed[res * res * 12:].view(torch.int32)))
+            ok = bool(torch.equal(frame_rgb[k].reshape(-1).view(torch.int32), ref_packed[: res * res * 12].view(torch.int32))
+                      and torch.equal(frame_hit[k].reshape(-1), ref_packed[res * res * 12:].view(torch.int32)))
         gather_check = "ok" if ok else "MISMATCH"
 
     if rank == 0:
@@ -244,9 +268,9 @@ def main():
                        "tile_order": args.tile_order,
                        "parallelism": "image rows in %d-row stripes, round-robin over %d GPU(s)%s"
                                       % (stripe_h, world,
-                                         "; one RCCL gather per frame of the %s to rank 0, double-buffered; "
-                                         "gathered frame vs single-GPU frame: %s"
-                                         % ("u8 image" if args.gather == "u8" else "float RGB + hit IDs", gather_check)
+                                         "; every frame's %s gathered to rank 0 over RCCL, %d frames per collective, "
+                                         "double-buffered; gathered frame vs single-GPU frame: %s"
+                                         % ("u8 image" if args.gather == "u8" else "float RGB + hit IDs", B, gather_check)
                                          if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,

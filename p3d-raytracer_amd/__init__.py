@@ -383,22 +383,27 @@ def packed_bytes(n_pixels):
     return n_pixels * 16
 
 
-def assemble_frame(gathered, res, world, stripe_h, frame_rgb=None, frame_hit=None):
-    """De-interleave the per-rank stripe buffers (torch uint8 tensors laid out as packed_bytes)
-    into the full frame: stripe s of rank r holds frame rows (s*world + r)*stripe_h ... +stripe_h."""
+def assemble_frame(gathered, res, world, stripe_h, frame_rgb=None, frame_hit=None, batch=1):
+    """De-interleave the per-rank stripe buffers (torch uint8 tensors, `batch` consecutive frames each
+    laid out as packed_bytes) into full frames: stripe s of rank r holds frame rows
+    (s*world + r)*stripe_h ... +stripe_h.  Returns (rgb, hit) of shape (ry, rx, 3) / (ry, rx), with a
+    leading batch axis when batch > 1."""
     import torch
     rx, ry = res
     n_str = ry // (stripe_h * world)
     n_local = rx * (ry // world)
     dev = gathered[0].device
     if frame_rgb is None:
-        frame_rgb = torch.empty((ry, rx, 3), dtype=torch.float32, device=dev)
+        frame_rgb = torch.empty((batch, ry, rx, 3), dtype=torch.float32, device=dev)
     if frame_hit is None:
-        frame_hit = torch.empty((ry, rx), dtype=torch.int32, device=dev)
-    parts = [g[: n_local * 12].view(torch.float32).view(n_str, stripe_h, rx, 3) for g in gathered]
-    frame_rgb.view(n_str, world, stripe_h, rx, 3).copy_(torch.stack(parts, dim=1))
-    hits = [g[n_local * 12: n_local * 16].view(torch.int32).view(n_str, stripe_h, rx) for g in gathered]
-    frame_hit.view(n_str, world, stripe_h, rx).copy_(torch.stack(hits, dim=1))
+        frame_hit = torch.empty((batch, ry, rx), dtype=torch.int32, device=dev)
+    per_frame = [g.view(batch, n_local * 16) for g in gathered]
+    parts = [g[:, : n_local * 12].contiguous().view(torch.float32).view(batch, n_str, stripe_h, rx, 3) for g in per_frame]
+    frame_rgb.view(batch, n_str, world, stripe_h, rx, 3).copy_(torch.stack(parts, dim=2))
+    hits = [g[:, n_local * 12:].contiguous().view(torch.int32).view(batch, n_str, stripe_h, rx) for g in per_frame]
+    frame_hit.view(batch, n_str, world, stripe_h, rx).copy_(torch.stack(hits, dim=2))
+    if batch == 1:
+        return frame_rgb.view(ry, rx, 3), frame_hit.view(ry, rx)
     return frame_rgb, frame_hit
 
 
@@ -406,8 +411,8 @@ _GATHER_MODE = {"mode": "gather"}
 
 
 def gather_frame(local_buf, res, rank, world, stripe_h, dst=0, gathered=None, async_op=False):
-    """One collective per frame: every rank's packed stripe buffer to rank `dst` (RCCL on GPUs,
-    gloo in the CPU tests).  Returns (work handle or None, gather list or None).
+    """One collective for a frame (or a batch of frames, rendered back to back into one buffer): every
+    rank's packed stripe buffer to rank `dst` (RCCL on GPUs, gloo in the CPU tests).  Returns (work handle or None, gather list or None).
     `gather` is the natural all-to-one; should a backend build not provide it, the first failure
     switches this process group to `all_gather` (same bytes into rank `dst`, the other ranks simply
     ignore what they receive) - every rank hits the same error at the same call, so they switch
@@ -428,16 +433,16 @@ def gather_frame(local_buf, res, rank, world, stripe_h, dst=0, gathered=None, as
     return work, gathered
 
 
-def assemble_frame8(gathered, res, world, stripe_h, frame8=None):
-    """Same de-interleave for the u8 frame (img_Data, 3 B/pixel): the payload bench.py gathers by default."""
+def assemble_frame8(gathered, res, world, stripe_h, frame8=None, batch=1):
+    """Same de-interleave for u8 frames (img_Data, 3 B/pixel): the payload bench.py gathers by default."""
     import torch
     rx, ry = res
     n_str = ry // (stripe_h * world)
     if frame8 is None:
-        frame8 = torch.empty((ry, rx, 3), dtype=torch.uint8, device=gathered[0].device)
-    parts = [g.view(n_str, stripe_h, rx, 3) for g in gathered]
-    frame8.view(n_str, world, stripe_h, rx, 3).copy_(torch.stack(parts, dim=1))
-    return frame8
+        frame8 = torch.empty((batch, ry, rx, 3), dtype=torch.uint8, device=gathered[0].device)
+    parts = [g.view(batch, n_str, stripe_h, rx, 3) for g in gathered]
+    frame8.view(batch, n_str, world, stripe_h, rx, 3).copy_(torch.stack(parts, dim=2))
+    return frame8.view(ry, rx, 3) if batch == 1 else frame8
 
 
 SKYBOX_FACE_FILES = ("right", "left", "top", "bottom", "front", "back")  # scene.cpp:333

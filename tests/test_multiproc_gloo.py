@@ -52,11 +52,24 @@ def _worker(rank, world, port, out_path, mode="gather"):
     assert buf.numel() == p3d.packed_bytes(n_local)
     work, gathered = p3d.gather_frame(buf, (RES, RES), rank, world, STRIPE_H, dst=0, async_op=True)
     work.wait()
+    # a batch of three frames in one collective (bench.py --gather-batch): frame 1 is the real one
+    junk = torch.full_like(buf, 7)
+    work3, gathered3 = p3d.gather_frame(torch.cat([junk, buf, junk]), (RES, RES), rank, world, STRIPE_H, dst=0, async_op=True)
+    work3.wait()
+    u8 = torch.from_numpy((rgb * 255).astype(np.uint8).reshape(-1).copy())
+    work8, gathered8 = p3d.gather_frame(torch.cat([u8, u8 // 2]), (RES, RES), rank, world, STRIPE_H, dst=0, async_op=True)
+    work8.wait()
     if rank == 0:
         frame_rgb, frame_hit = p3d.assemble_frame(gathered, (RES, RES), world, STRIPE_H)
         full_rgb, full_hit, _ = sc.render(cfg)
         ok = bool((frame_rgb.numpy().view(np.uint32) == full_rgb.view(np.uint32)).all()
                   and (frame_hit.numpy() == full_hit).all())
+        b_rgb, b_hit = p3d.assemble_frame(gathered3, (RES, RES), world, STRIPE_H, batch=3)
+        ok = ok and b_rgb.shape == (3, RES, RES, 3) and bool((b_rgb[1].numpy().view(np.uint32) == full_rgb.view(np.uint32)).all()
+                                                             and (b_hit[1].numpy() == full_hit).all())
+        f8 = p3d.assemble_frame8(gathered8, (RES, RES), world, STRIPE_H, batch=2)
+        full8 = (full_rgb * 255).astype(np.uint8)
+        ok = ok and bool((f8[0].numpy() == full8).all() and (f8[1].numpy() == full8 // 2).all())
         with open(out_path, "w") as f:
             f.write("ok" if ok else "mismatch")
     dist.barrier()
