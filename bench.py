@@ -256,6 +256,14 @@ def main():
         prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm_bytes.json")
         if os.path.exists(prof) and args.workload == "cfg2" and world == 1:
             traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+        valu = None
+        pmc = os.path.join(ROOT, "profiles", "r01", "cfg2_pmc_summary.json")
+        if os.path.exists(pmc) and args.workload == "cfg2" and world == 1 and kernel_ms > 0:
+            # the ceiling that does apply: a wave64 VALU instruction holds its SIMD for
+            # 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz; instruction count from the committed PMC pass
+            insts = json.load(open(pmc))["SQ_INSTS_VALU"]["mean"]
+            floor_ms = insts * 4 / (1024 * 2.4e9) * 1e3
+            valu = {"wave_instructions": int(insts), "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / kernel_ms, 4)}
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -276,6 +284,7 @@ def main():
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                          "kernel": "whitted_kernel" if cfg.integrator == p3d.WHITTED or not cfg.antialiasing else "pt_kernel",
                          "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_launch),
+                         "valu_issue": valu,
                          "note": "algorithmic bytes (DESIGN.md) are served from LDS/L2, not HBM: the kernel is "
                                  "VALU/latency bound; traffic = measured HBM bytes"},
         }
