@@ -28,7 +28,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "tri100k", "cornell_pt"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "tri100k", "cornell_pt"],
                     help="cfg2 (default) = BASELINE configs[1]; cfg3/cfg4/cfg5 = configs[2]/[3]/[4] at their full sizes; "
                          "tri100k / cornell_pt = the same scenes at quick sizes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -49,6 +49,9 @@ def parse():
 def workload_setup(name, n_gpus, p3d):
     """-> (scene path, config, base resolution, description)"""
     scenes = os.path.join(ROOT, "tests", "golden", "scenes")
+    if name == "cfg1":  # BASELINE configs[0]: the reference's own CPU-runnable case, fixed 512x512
+        return (os.path.join(scenes, "balls_low.p3f"), p3d.whitted_config(accel=p3d.ACCEL_NONE, max_depth=1), -512,
+                "balls_low.p3f 512x512, Whitted MAX_DEPTH=1, no acceleration structure (BASELINE configs[0])")
     if name == "cfg2":
         return (os.path.join(scenes, "balls_low.p3f"), p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4), 1024,
                 "balls_low.p3f, Whitted MAX_DEPTH=4, BVH, no AA (BASELINE configs[1])")
@@ -309,7 +312,7 @@ def cpu_baseline(workload, scene_path, cfg, res):
                              depth_of_field=cfg.depth_of_field, sample_disk=cfg.sample_disk,
                              soft_shadows=cfg.soft_shadows, sample_mode=cfg.sample_mode, seed=cfg.seed,
                              rng_mode=0, stack_mode=1, trace_zero_weight=1, math_mode=0, threads=1)
-    if workload == "cfg2":
+    if workload in ("cfg1", "cfg2"):
         x0 = y0 = 0
         w = h = res
         reps = 5
