@@ -31,7 +31,20 @@ def _ensure_built():
 
 
 def scene_path(name):
-    return os.path.join(SCENES, name)
+    """Path of a packaged scene; the big ones are stored gzipped and unpacked once per user into /tmp."""
+    plain = os.path.join(SCENES, name)
+    if os.path.exists(plain) or not os.path.exists(plain + ".gz"):
+        return plain
+    import gzip
+    import shutil
+    cache = os.path.join("/tmp", "p3d_scenes_%d" % os.getuid())
+    os.makedirs(cache, exist_ok=True)
+    out = os.path.join(cache, name)
+    if not os.path.exists(out):
+        with gzip.open(plain + ".gz", "rb") as src, open(out + ".tmp%d" % os.getpid(), "wb") as dst:
+            shutil.copyfileobj(src, dst)
+        os.replace(out + ".tmp%d" % os.getpid(), out)
+    return out
 
 
 @pytest.fixture(scope="session")

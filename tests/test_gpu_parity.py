@@ -451,10 +451,10 @@ def test_axis_parallel_rays_and_nan_semantics(accel):
     assert (dev.trace_any(accel, q_o, q_d) == sc.trace_any(accel, q_o, q_d)).all()
 
 
-@pytest.mark.parametrize("scene", ["balls_high.p3f", "mount_high.p3f"])
+@pytest.mark.parametrize("scene", ["balls_high.p3f", "mount_high.p3f", "mount_very_high.p3f"])
 @pytest.mark.parametrize("accel", [p3d.ACCEL_GRID, p3d.ACCEL_BVH])
 def test_large_packaged_scenes(scene, accel):
-    """the big packaged scenes (7 381 spheres / 2 048 triangles, legacy `f` lines) as
+    """the big packaged scenes (7 381 spheres / 2 048 and 32 768 triangles, legacy `f` lines) as
     BVH and grid stress inputs: too large for LDS staging, deep trees, many sphere re-normalisations."""
     dev, sc = _pair(scene_path(scene), res=(160, 160), legacy=True)
     cfg = p3d.whitted_config(accel=accel, max_depth=3, collect_stats=1)
