@@ -251,6 +251,16 @@ void p3d_config_default(p3d_config* cfg);  /* constants.h:6-45 as shipped */
 /* ---- scene on the device ---- */
 /* Uploads the flattened scene to HBM of HIP device `device` (arrays copied). */
 int p3d_scene_create(const p3d_scene_desc* desc, int device, p3d_scene** out);
+/*
+ * Same, but the BVH is built ON the GPU (linear BVH: Morton codes of the bounding-box centres,
+ * radix sort, Karras hierarchy, bottom-up refit) instead of being uploaded; the descriptor's bvh_*
+ * arrays are ignored, prims[].bmin/bmax must hold GetBoundingBox().  NOT the reference's tree
+ * (bvh.cpp:89-196): closest-hit queries find the same nearest intersection (exact-t ties aside),
+ * but the any-hit quirk of bvh.cpp:329-334 depends on the tree shape, so Whitted shadow feelers
+ * can differ from a scene created with the reference-exact tree.  For callers who want correct
+ * closest hits without waiting for the host build.  *build_ms (may be NULL): GPU time of the build.
+ */
+int p3d_scene_create_device_bvh(const p3d_scene_desc* desc, int device, p3d_scene** out, float* build_ms);
 void p3d_scene_destroy(p3d_scene* scene);
 
 /*

@@ -28,7 +28,7 @@ LOAD_LEGACY_F11 = 1
 
 EXPORTS = [
     "p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_config_default",
-    "p3d_scene_create", "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_render_tile", "p3d_render_tile_device",
+    "p3d_scene_create", "p3d_scene_create_device_bvh", "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_render_tile", "p3d_render_tile_device",
     "p3d_trace_closest", "p3d_trace_any", "p3d_host_scene_load", "p3d_host_scene_destroy",
     "p3d_host_scene_set_resolution", "p3d_host_scene_set_lens", "p3d_host_scene_replicate_lights",
     "p3d_host_scene_desc",
@@ -290,12 +290,21 @@ class DeviceScene:
     """p3d_scene_create: the flattened scene resident in HBM of one MI355X."""
 
     def __init__(self, host_scene, bvh=True, grid=False, device=0):
+        """bvh: True = the reference-exact tree built on the host (BVH::build), "device" = a linear BVH built
+        on the GPU (p3d_scene_create_device_bvh: correct closest hits, not the reference's tree), False = none."""
         self._L = lib()
         self.host = host_scene
-        d = host_scene.desc(bvh, grid)
-        self.res = (d.camera.res_x, d.camera.res_y)
+        self.device_bvh_ms = None
         h = C.c_void_p()
-        _check(self._L.p3d_scene_create(C.byref(d), int(device), C.byref(h)))
+        if bvh == "device":
+            d = host_scene.desc(False, grid)
+            ms = C.c_float(0)
+            _check(self._L.p3d_scene_create_device_bvh(C.byref(d), int(device), C.byref(h), C.byref(ms)))
+            self.device_bvh_ms = ms.value
+        else:
+            d = host_scene.desc(bool(bvh), grid)
+            _check(self._L.p3d_scene_create(C.byref(d), int(device), C.byref(h)))
+        self.res = (d.camera.res_x, d.camera.res_y)
         self._h = h
         self.device = device
 

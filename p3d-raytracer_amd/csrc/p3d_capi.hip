@@ -11,6 +11,7 @@
 
 #include "../host/p3d_error.hpp"
 #include "kernels.hpp"
+#include "lbvh.hpp"
 #include "p3d.h"
 #include "pt_kernel.hpp"
 
@@ -93,6 +94,7 @@ struct p3d_scene {
   DevScene dev{};
   bool has_bvh = false, has_grid = false;
   uint32_t bvh_max_depth = 0;
+  float device_bvh_ms = 0;  // GPU time of lbvh::build, 0 for an uploaded tree
   Scratch levels, spill, out_rgb, out_hit, out_rgb8, q_in, q_out;
   unsigned long long* d_stats = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -128,8 +130,18 @@ void p3d_scene_destroy(p3d_scene* s) {
   delete s;
 }
 
-int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
-  if (!d || !out) return fail(P3D_ERR_INVALID, "p3d_scene_create: null argument");
+// device_bvh: the BVH arrays of the descriptor are ignored and a linear BVH is built on the GPU (lbvh.hpp)
+static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, p3d_scene** out) {
+  if (!d_in || !out) return fail(P3D_ERR_INVALID, "p3d_scene_create: null argument");
+  p3d_scene_desc d_local = *d_in;
+  if (device_bvh) {  // sizes of the device-built tree: 2 n - 1 nodes, one leaf slot per object
+    d_local.n_bvh_nodes = 0; d_local.bvh_nodes = nullptr;
+    d_local.n_bvh_prim_index = 0; d_local.bvh_prim_index = nullptr;
+    d_local.bvh_max_depth = 0;
+  }
+  const p3d_scene_desc* d = &d_local;
+  const uint32_t lbvh_nodes = device_bvh && d->n_prims ? 2 * d->n_prims - 1 : 0;
+  const uint32_t lbvh_slots = device_bvh ? d->n_prims : 0;
   if (d->abi_version != P3D_ABI_VERSION) return fail(P3D_ERR_INVALID, "p3d_scene_create: ABI version mismatch");
   if ((d->n_prims && !d->prims) || (d->n_materials && !d->materials) || (d->n_lights && !d->lights))
     return fail(P3D_ERR_INVALID, "p3d_scene_create: null array with non-zero count");
@@ -193,7 +205,9 @@ int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
     blob.push_back(make_float4(n.bmin[0], n.bmin[1], n.bmin[2], descf));
     blob.push_back(make_float4(n.bmax[0], n.bmax[1], n.bmax[2], 0.f));
   }
+  blob.resize(blob.size() + (size_t)2 * lbvh_nodes, make_float4(0, 0, 0, 0));  // filled in by lbvh::build
   s->off_bgeom = (uint32_t)blob.size();
+  blob.resize(blob.size() + (size_t)3 * lbvh_slots, make_float4(0, 0, 0, 0));
   for (uint32_t i = 0; i < d->n_bvh_prim_index; ++i) {
     float4 g[3];
     geom_of(d->bvh_prim_index[i], g);
@@ -256,6 +270,27 @@ int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
   v.cam.aperture = c.aperture; v.cam.res_x = c.res_x; v.cam.res_y = c.res_y;
   v.bg = to_f3(d->background);
   s->has_bvh = d->n_bvh_nodes > 0;
+  if (device_bvh && d->n_prims) {
+    if (d->n_prims > 0x07ffffffu) return fail(P3D_ERR_CAPACITY, "p3d_scene_create_device_bvh: too many objects");
+    std::vector<float4> boxes((size_t)2 * d->n_prims);
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+      boxes[2 * i] = make_float4(d->prims[i].bmin[0], d->prims[i].bmin[1], d->prims[i].bmin[2], 0.f);
+      boxes[2 * i + 1] = make_float4(d->prims[i].bmax[0], d->prims[i].bmax[1], d->prims[i].bmax[2], 0.f);
+    }
+    float4* d_boxes = nullptr;
+    P3D_HIP(hipMalloc((void**)&d_boxes, boxes.size() * sizeof(float4)));
+    hipError_t e = hipMemcpy(d_boxes, boxes.data(), boxes.size() * sizeof(float4), hipMemcpyHostToDevice);
+    lbvh::Result built;
+    if (e == hipSuccess)
+      e = lbvh::build(d_boxes, s->d_blob + s->off_ogeom, d->n_prims, s->d_blob + s->off_nodes, s->d_blob + s->off_bgeom, &built);
+    (void)hipFree(d_boxes);
+    if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("device BVH build: ") + hipGetErrorString(e));
+    v.n_nodes = built.n_nodes;
+    v.n_slots = d->n_prims;
+    s->has_bvh = true;
+    s->bvh_max_depth = built.max_depth;
+    s->device_bvh_ms = built.build_ms;
+  }
   // The node-stack capacity (LDS + spill) is derived from the tree depth: never trust the caller's
   // number below what the node array really contains (child indices were validated above:
   // children lie behind their parent, so this walk terminates).
@@ -270,7 +305,7 @@ int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
       if (!(n.count_leaf & P3D_BVH_LEAF)) level[n.index] = level[n.index + 1] = level[i] + 1;
     }
   }
-  s->bvh_max_depth = std::max(d->bvh_max_depth, real_depth);
+  if (!device_bvh) s->bvh_max_depth = std::max(d->bvh_max_depth, real_depth);
   if (d->has_grid) {
     const p3d_grid_desc& g = d->grid;
     P3D_HIP(hipMalloc((void**)&s->d_cell_start, (size_t)(g.n_cells + 1) * 4));
@@ -287,6 +322,14 @@ int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) {
   P3D_HIP(hipEventCreate(&s->ev1));
   *out = s.release();
   return P3D_OK;
+}
+
+int p3d_scene_create(const p3d_scene_desc* d, int device, p3d_scene** out) { return create_impl(d, device, false, out); }
+
+int p3d_scene_create_device_bvh(const p3d_scene_desc* d, int device, p3d_scene** out, float* build_ms) {
+  const int rc = create_impl(d, device, true, out);
+  if (rc == P3D_OK && build_ms) *build_ms = (*out)->device_bvh_ms;
+  return rc;
 }
 
 }  // extern "C"

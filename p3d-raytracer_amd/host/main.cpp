@@ -6,6 +6,8 @@
 //   p3d_render [scene.p3f] [--whitted|--pathtrace] [--accel none|grid|bvh] [--depth N]
 //              [--spp N(sqrt)] [--aa 0|1] [--dof 0|1] [--soft 0|1] [--tent] [--gamma G]
 //              [--res W H] [--seed S] [--legacy-f11] [--out image.ppm] [--device D]
+//              [--device-bvh]   build a linear BVH on the GPU instead of the reference's tree on the host
+//                               (p3d_scene_create_device_bvh: same closest hits, shadow feelers may differ)
 //              [--skybox DIR]   DIR/{right,left,top,bottom,front,back}.ppm (binary P6; convert the
 //                               reference's JPEGs once with scenes/skybox_to_ppm.py) -> SKYBOX true
 #include <chrono>
@@ -61,6 +63,7 @@ int main(int argc, char** argv) {
   p3d_config_default(&cfg);
   std::string scene_path, skybox_dir, out = "RT_Output.ppm";  // main.cpp:851 writes RT_Output.png
   int res_w = 0, res_h = 0, device = 0;
+  bool device_bvh = false;
   uint32_t load_flags = 0;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -86,6 +89,7 @@ int main(int argc, char** argv) {
     else if (a == "--out") out = next("--out");
     else if (a == "--skybox") skybox_dir = next("--skybox");
     else if (a == "--device") device = std::atoi(next("--device"));
+    else if (a == "--device-bvh") device_bvh = true;
     else if (a[0] != '-') scene_path = a;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
@@ -108,11 +112,17 @@ int main(int argc, char** argv) {
 
   const auto t_build0 = std::chrono::high_resolution_clock::now();
   const p3d_scene_desc* desc = nullptr;
-  if (p3d_host_scene_desc(hs, cfg.accel == P3D_ACCEL_BVH, cfg.accel == P3D_ACCEL_GRID, &desc) != P3D_OK) return die("flatten");
+  if (p3d_host_scene_desc(hs, cfg.accel == P3D_ACCEL_BVH && !device_bvh, cfg.accel == P3D_ACCEL_GRID, &desc) != P3D_OK) return die("flatten");
   const int W = desc->camera.res_x, H = desc->camera.res_y;
   std::printf("\nResolutionX = %d  ResolutionY= %d.\n", W, H);  // main.cpp:986
   p3d_scene* scene = nullptr;
-  if (p3d_scene_create(desc, device, &scene) != P3D_OK) return die("scene_create");
+  if (device_bvh && cfg.accel == P3D_ACCEL_BVH) {
+    float build_ms = 0;
+    if (p3d_scene_create_device_bvh(desc, device, &scene, &build_ms) != P3D_OK) return die("scene_create_device_bvh");
+    std::printf("BVH built on the GPU in %.2f ms\n", build_ms);
+  } else if (p3d_scene_create(desc, device, &scene) != P3D_OK) {
+    return die("scene_create");
+  }
   if (!skybox_dir.empty()) {  // Scene::LoadSkybox (scene.cpp:329-377) + SKYBOX true (constants.h:30)
     static const char* names[6] = {"right", "left", "top", "bottom", "front", "back"};
     std::vector<uint8_t> bytes[6];
