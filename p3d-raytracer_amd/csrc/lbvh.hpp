@@ -10,8 +10,8 @@
 //      covers the key range that shares the longest common prefix around position i
 //   4. bottom-up box refit (second child to arrive continues to the parent)
 //   5. emission in the layout the traversal kernels read (device_core.hpp): node 0 = root, the two
-//      children of internal node i at 1 + 2 i and 2 + 2 i, one object per leaf, leaf geometry
-//      gathered in leaf order
+//      children of internal node i at 1 + 2 i and 2 + 2 i, one or two objects per leaf, leaf
+//      geometry gathered in leaf order
 // Object boxes are the GetBoundingBox() values of p3d_prim (planes: the [-1,1]^3 default, Q12).
 #pragma once
 
@@ -144,8 +144,18 @@ __global__ void refit(const unsigned long long* keys, const float4* boxes, uint3
   atomicMax(leaf_depth_max, depth + 0u);
 }
 
-__device__ __forceinline__ void emit_record(float4* nodes, uint32_t at, const float4* node_box, uint32_t ref) {
-  const uint32_t desc = (ref & 1u) ? (kDescLeaf | (1u << 28) | (ref >> 1)) : (1u + 2u * (ref >> 1));
+// An internal node whose two children are both leaves is emitted as ONE leaf of two objects (their
+// slots are adjacent: the split lies between them), as the reference's trees have (Threshold 2,
+// bvh.cpp:83): half the leaf-level box tests for one more object test; its own pair of child
+// records stays unused.
+__device__ __forceinline__ void emit_record(float4* nodes, uint32_t at, const float4* node_box, const uint2* children, uint32_t ref) {
+  uint32_t desc;
+  if (ref & 1u) {
+    desc = kDescLeaf | (1u << 28) | (ref >> 1);
+  } else {
+    const uint2 ch = children[ref >> 1];
+    desc = (ch.x & ch.y & 1u) ? (kDescLeaf | (2u << 28) | (ch.x >> 1)) : (1u + 2u * (ref >> 1));
+  }
   const float4 lo = node_box[2 * ref], hi = node_box[2 * ref + 1];
   nodes[2 * at] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(desc));
   nodes[2 * at + 1] = make_float4(hi.x, hi.y, hi.z, 0.f);
@@ -159,14 +169,14 @@ __global__ void emit(const unsigned long long* keys, uint32_t n, const uint2* ch
     for (int q = 0; q < 3; ++q) bgeom[3 * i + q] = ogeom[3 * obj + q];
   }
   if (n == 1) {
-    if (i == 0) emit_record(nodes, 0, node_box, 1u);  // the root is the only leaf
+    if (i == 0) emit_record(nodes, 0, node_box, children, 1u);  // the root is the only leaf
     return;
   }
   if (i < n - 1) {
     const uint2 ch = children[i];
-    emit_record(nodes, 1 + 2 * i, node_box, ch.x);
-    emit_record(nodes, 2 + 2 * i, node_box, ch.y);
-    if (i == 0) emit_record(nodes, 0, node_box, 0u);
+    emit_record(nodes, 1 + 2 * i, node_box, children, ch.x);
+    emit_record(nodes, 2 + 2 * i, node_box, children, ch.y);
+    if (i == 0) emit_record(nodes, 0, node_box, children, 0u);
   }
 }
 
