@@ -20,7 +20,9 @@
 #include "kernels.hpp"
 
 #ifndef P3D_PT_WAVES
-#define P3D_PT_WAVES 3  // minimum waves per SIMD asked of the register allocator (2: 6.4 ms, 3: 5.6 ms, 4: 6.0 ms + spills on cornell 512x512x16spp)
+#define P3D_PT_WAVES 4  // minimum waves per SIMD asked of the register allocator: 128 VGPRs, 12-15 spilled dwords for the BVH
+                        // instantiations.  cfg3: 3 waves 190 ms, 4 waves 160 ms, 5 waves (96 VGPRs, 51 spilled) 177 ms.  (Before the
+                        // deferred dielectric branches left LDS, 4 waves did not fit and 3 was the optimum.)
 #endif
 
 namespace p3d {
