@@ -18,6 +18,13 @@
 #ifndef P3D_WHITTED_WAVES
 #define P3D_WHITTED_WAVES 2
 #endif
+// Same for the no-AA instantiations that traverse the scene from L2: they wait on memory, not on the VALU, and
+// trade registers for waves.  100k triangles 1024x1024 / 2048x2048 with 16 / 12 / 12 / 10 / 8 LDS stack entries:
+// 4 waves (111 VGPRs) 8.44 / 22.9 ms, 5 (96) 7.69 / 20.7, 6 (80 VGPRs, 46 spilled dwords) 7.26 / 19.4,
+// 7 (72) 7.40 / 18.7, 8 (64) 7.37 / 18.7.
+#ifndef P3D_WHITTED_GLOBAL_WAVES
+#define P3D_WHITTED_GLOBAL_WAVES 6
+#endif
 
 namespace p3d {
 
@@ -240,7 +247,7 @@ __device__ __forceinline__ void make_primary(const RenderParams& P, const DevCam
 // Whitted megakernel
 // ---------------------------------------------------------------------------
 template <int ACCEL, bool LDS, bool STATS, bool AA>
-__global__ void __launch_bounds__(kBlock, P3D_WHITTED_WAVES) whitted_kernel(const RenderParams P) {
+__global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_WHITTED_GLOBAL_WAVES) whitted_kernel(const RenderParams P) {
   extern __shared__ float4 smem[];
   uint32_t tx, ty;
   if (!tile_of_block(P, tx, ty)) return;

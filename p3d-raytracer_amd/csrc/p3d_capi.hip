@@ -494,10 +494,10 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // which holds the first `cap` entries in LDS and spills the rest.
   const uint32_t bound = stack_bound(s, cfg->accel, !pt);
   const bool lds_scene = (size_t)s->blob_f4 * sizeof(float4) <= kLdsSceneLimitBytes && bound <= 24;
-  // LDS part of the node stack of a scene traversed from L2: at most 16 entries (8 KB per wave), so that 16 waves
-  // fit the CU's 160 KB as the registers allow; deeper entries spill.  (24 entries = 13 waves: 100k triangles
-  // 1024x1024 9.94 ms, 16 entries 8.43 ms, 12: 8.43, 8: 8.56.)
-  const uint32_t depth_cap = std::min<uint32_t>(std::max<uint32_t>(s->bvh_max_depth + 3, 8), 16);
+  // LDS part of the node stack of a scene traversed from L2: at most 12 entries (6 KB per wave), so that the 24
+  // waves per CU the registers of the no-AA kernel allow also fit its 160 KB of LDS; deeper entries spill to global
+  // memory.  (24 entries = 13 waves per CU: 100k triangles 1024x1024 9.94 ms; 16 entries 8.43 ms at 4 waves per SIMD.)
+  const uint32_t depth_cap = std::min<uint32_t>(std::max<uint32_t>(s->bvh_max_depth + 3, 8), 12);
   const uint32_t cap = cfg->accel == P3D_ACCEL_BVH ? (lds_scene ? bound : std::min(bound, depth_cap)) : 1;
   const uint32_t spill_entries = bound > cap ? bound - cap : 0;
   const bool want_counts = stats && cfg->collect_stats;
