@@ -98,6 +98,7 @@ struct RenderParams {
   //   sched: see sched_build_kernel.   tile_cost[t]: wall-clock ticks the workgroup of tile t was resident.
   const uint32_t* sched;
   uint32_t* tile_cost;
+  uint32_t stack_spills;  // LDS-staged scene with the spilling stack (host-side kernel choice)
 };
 
 // LDS map of one workgroup:  [ staged scene (lds_scene_f4 float4) | node stack (cap * 64 * 8 B) | per-pixel sample ring (PT, 4 lanes per pixel) ]
@@ -246,7 +247,7 @@ __device__ __forceinline__ void make_primary(const RenderParams& P, const DevCam
 // ---------------------------------------------------------------------------
 // Whitted megakernel
 // ---------------------------------------------------------------------------
-template <int ACCEL, bool LDS, bool STATS, bool AA>
+template <int ACCEL, bool LDS, bool STATS, bool AA, bool SPILL = !LDS>
 __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_WHITTED_GLOBAL_WAVES) whitted_kernel(const RenderParams P) {
   extern __shared__ float4 smem[];
   uint32_t tx, ty;
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
           PT_REGION(1)
           F3 Pn;
           Geom g;
-          const int obj = closest_hit<ACCEL, !LDS>(sc, st, ray, Pn, g, ct);
+          const int obj = closest_hit<ACCEL, SPILL>(sc, st, ray, Pn, g, ct);
           PT_REGION(2)
           if (level == 0 && si == 0 && sj == 0) first_hit = obj;
           if (obj < 0) {  // main.cpp:144-147
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
               ray_set(feeler, intercept, l_dir);
               ct.add(kRaysShadow);
               PT_REGION(4)
-              const bool shadowed = any_hit<ACCEL, !LDS>(sc, st, feeler, ct);
+              const bool shadowed = any_hit<ACCEL, SPILL>(sc, st, feeler, ct);
               PT_REGION(5)
               const F3 blinn = normalized((l_dir + get_direction(ray) * -1.0f) / 2);
               if (!shadowed) {  // main.cpp:222-225: max() and pow() evaluate in double
