@@ -30,7 +30,8 @@ namespace {
 #define P3D_PT_SUB4_MIN_SPP_SQRT 4
 #endif
 constexpr uint32_t kPtSub4MinSppSqrt = P3D_PT_SUB4_MIN_SPP_SQRT;  // from 16 samples per pixel: 4 lanes per pixel
-constexpr uint32_t kLdsSceneLimitBytes = 16 * 1024;  // stage the scene in LDS up to this size
+constexpr uint32_t kLdsSceneLimitBytesPt = 16 * 1024;  // same for the path tracer (not re-tuned: its packaged scenes are 1-2 KB)
+constexpr uint32_t kLdsSceneLimitBytes = 26 * 1024;  // stage the scene in LDS up to this size
 // A frame is rendered by as few launches as the per-thread scratch (level records + stack spill)
 // allows: every launch ends with a tail of partly idle CUs (2048x2048, 100k triangles: 30.3 ms in
 // two launches, 28.1 ms in one).
@@ -496,12 +497,13 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // (kernel variant without a spill path); deep trees / many lights use the global-memory variant,
   // which holds the first `cap` entries in LDS and spills the rest.
   const uint32_t bound = stack_bound(s, cfg->accel, !pt);
-  // A scene of up to 16 KB is staged in LDS.  If its worst-case stack has at most 24 entries the whole stack lives
-  // in LDS too (kernel without a spill path); otherwise (Whitted, several lights, deeper tree) the staged scene is
-  // combined with the spilling stack: balls_medium 0.48 -> 0.40 ms, balls_box 0.42 -> 0.32 ms against traversing
-  // those 14 KB from L2.
-  const bool lds_scene = (size_t)s->blob_f4 * sizeof(float4) <= kLdsSceneLimitBytes && (bound <= 24 || !pt);
-  const bool lds_spill = lds_scene && bound > 24;
+  // A scene of up to 26 KB is staged in LDS (beyond that the waves a CU can hold get too few: 37 KB staged
+  // 1.22 ms, from L2 0.76 ms).  If scene + worst-case stack fit 20 KB and the stack has at most 24 entries, the
+  // whole stack lives in LDS too (kernel without a spill path); otherwise (Whitted, several lights, deeper tree)
+  // the staged scene is combined with the spilling stack: balls_medium 0.48 -> 0.40 ms, balls_box 0.42 -> 0.32 ms,
+  // 96 / 128 random objects 0.49 -> 0.42 / 0.75 -> 0.66 ms against traversing those 14-25 KB from L2.
+  const bool lds_scene = (size_t)s->blob_f4 * sizeof(float4) <= (pt ? kLdsSceneLimitBytesPt : kLdsSceneLimitBytes) && (bound <= 24 || !pt);
+  const bool lds_spill = lds_scene && !pt && (bound > 24 || (size_t)s->blob_f4 * sizeof(float4) + (size_t)bound * kBlock * sizeof(uint2) > 20 * 1024);
   // LDS part of the node stack of a scene traversed from L2: at most 12 entries (6 KB per wave), so that the 24
   // waves per CU the registers of the no-AA kernel allow also fit its 160 KB of LDS; deeper entries spill to global
   // memory.  (24 entries = 13 waves per CU: 100k triangles 1024x1024 9.94 ms; 16 entries 8.43 ms at 4 waves per SIMD.)
