@@ -1,7 +1,7 @@
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r01f
+O=$R/gpurun_out/prof_r01g
 mkdir -p $O
 cd $R
 timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $O/trace --output-format csv -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_trace.json 2> $O/trace.err
