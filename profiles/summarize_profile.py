@@ -13,7 +13,7 @@ for f, name in (("bench_trace.json", "cfg2_bench_under_rocprof.json"), ("bench_t
                 ("bench_pt.json", "cornell_pt_bench_under_rocprof.json"), ("bench_plain.json", "cfg2_bench_plain.json")):
     shutil.copy(f"{src}/{f}", f"{dst}/{name}")
 
-KERNEL = "whitted_kernel<2, true, false, false>"  # the timed kernel of the default bench
+KERNEL = "whitted_kernel<2, true, false, false"  # the timed kernel of the default bench (any SPILL argument)
 vals = {}
 for path in glob.glob(f"{src}/pmc_*/*/*_counter_collection.csv"):
     with open(path) as fh:
