@@ -75,6 +75,7 @@ struct PtPixelShared {       // [..][pixel]: the 16 pixels of the tile are the f
   uint32_t next_start[16];   // next sample index to hand out (runs past the last sample: one ticket per finished lane)
   uint32_t next_add[16];     // next sample index to add to the pixel colour
   int32_t first_hit[16];
+  float colour[3][16];             // the pixel's running sum (kept here, not in lane 0's registers)
   uint32_t tag[kPtRing][16];       // sample index + 1 of the radiance in that ring slot
   float radiance[kPtRing][3][16];
 };
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
     shared.next_start[px] = 0;
     shared.next_add[px] = 0;
     shared.first_hit[px] = -1;
+    shared.colour[0][px] = 0.0f; shared.colour[1][px] = 0.0f; shared.colour[2][px] = 0.0f;
     for (int k = 0; k < kPtRing; ++k) shared.tag[k][px] = 0;
   }
 
@@ -148,7 +150,8 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
     // only way round, LLVM split the wait cycle off as an inner loop for the brute-force and grid
     // instantiations and the waiting lanes starved the working ones.)  The trip bound is a backstop:
     // no lane can need more trips than the pixel's whole sample set traced by one lane.
-    unsigned long long trips_left = (unsigned long long)n_samples * (unsigned)(MAXD + 2) * 4ull + 1024ull;
+    const unsigned long long trips_max = (unsigned long long)n_samples * (unsigned)(MAXD + 2) * 4ull + 1024ull;
+    uint32_t trips_left = trips_max > 0xffffffffull ? 0xffffffffu : (uint32_t)trips_max;
     bool done = false, holding = false;
     const uint32_t spp_magic = (uint32_t)((0x100000000ull + (unsigned)SPP - 1) / (unsigned)SPP);
     while (true) {
@@ -162,13 +165,16 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
       // whenever it is between two of its own samples, and every fourth trip while it traces one
       if (SUB == 4 && sub == 0 && (!alive || (trips_left & 3) == 0)) {
         uint32_t na = shared.next_add[px];
-        const uint32_t before = na;
-        while (na < (uint32_t)n_samples && shared.tag[na % kPtRing][px] == na + 1) {
-          const int k = (int)(na % kPtRing);
-          color = color + f3(shared.radiance[k][0][px], shared.radiance[k][1][px], shared.radiance[k][2][px]);
-          ++na;
+        if (na < (uint32_t)n_samples && shared.tag[na % kPtRing][px] == na + 1) {
+          F3 sum = f3(shared.colour[0][px], shared.colour[1][px], shared.colour[2][px]);
+          do {
+            const int k = (int)(na % kPtRing);
+            sum = sum + f3(shared.radiance[k][0][px], shared.radiance[k][1][px], shared.radiance[k][2][px]);
+            ++na;
+          } while (na < (uint32_t)n_samples && shared.tag[na % kPtRing][px] == na + 1);
+          shared.colour[0][px] = sum.x; shared.colour[1][px] = sum.y; shared.colour[2][px] = sum.z;
+          shared.next_add[px] = na;
         }
-        if (na != before) shared.next_add[px] = na;
       }
       if (!alive) {
         PT_REGION(1)
@@ -366,6 +372,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
         ct.add(kRaysBounce, 2);
       }
     }
+    if (SUB == 4 && sub == 0) color = f3(shared.colour[0][px], shared.colour[1][px], shared.colour[2][px]);
     if (P.antialiasing) color = color / (float)(SPP * SPP);  // main.cpp:800
 
 #ifdef P3D_PT_PROFILE
