@@ -5,7 +5,8 @@
 // the reference's scalar code rounds.
 //
 // Conventions
-//   * A wavefront (64 lanes) is one packet of rays = an 8x8 pixel block.  Traversal is
+//   * A wavefront (64 lanes) is one packet of rays = an 8x8 pixel block (path tracer from 16 spp:
+//     a 4x4 block, four lanes per pixel).  Traversal is
 //     PER LANE (own current node, own stack): the reference's any-hit traversal is
 //     order-dependent, so lanes cannot share a stack.  The wave as a
 //     whole iterates `while any lane is still walking`.
@@ -13,7 +14,7 @@
 //     (8 bytes: node index, entry distance).  A wave's 64 lanes then cover all 64 banks
 //     exactly twice per ds_read_b64/ds_write_b64 whatever their individual depths are,
 //     i.e. the access is bank-conflict free by construction.
-//   * Small scenes (every packaged .p3f) are staged into LDS once per workgroup; large
+//   * Scenes of up to 26 KB (most packaged .p3f) are staged into LDS once per workgroup; large
 //     ones (100k triangles = 8.8 MB) are read through L1/L2 from the linearised arrays.
 //   * Mixed-precision literals of the reference are folded into float comparisons where
 //     that is exact (see the cmp_* helpers); real double arithmetic stays double.

@@ -1,8 +1,9 @@
 // pt_kernel.hpp — the path tracer (Radiance, main.cpp:313-516) as a persistent per-lane
 // bounce loop.
 //
-// The reference recurses:  R = E + e + f * R(child).  Here every lane owns one pixel and
-// runs ONE flat loop whose body is a single bounce; a lane whose path ended starts its next
+// The reference recurses:  R = E + e + f * R(child).  Here every lane owns one pixel (or, from
+// 16 samples per pixel, a quarter of one: SUB = 4 below) and runs ONE flat loop whose body is
+// a single bounce; a lane whose path ended starts its next
 // sample (or pops its pending dielectric branch) in the same iteration instead of waiting
 // for the slowest lane of the wave, so the wave only idles lanes in the very last
 // iterations of a tile (the "persistent threads" bounce loop BASELINE.json asks for).  Radiance is carried as
