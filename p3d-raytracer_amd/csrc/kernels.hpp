@@ -286,130 +286,7 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
 #endif
     for (int si = 0; si < SPP; ++si) {
       for (int sj = 0; sj < SPP; ++sj) {
-        if (AA) rng.seed_stream(P.seed, (uint32_t)(y * sc.cam.res_x + x), (uint32_t)(si * SPP + sj));
-        st.sp = 0;  // hit_stack starts empty at every primary sample (DESIGN.md "Sequential state")
-        F3 o, d;
-        make_primary(P, sc.cam, x, y, si, sj, rng, o, d);
-        RayS ray;
-        ray_set(ray, o, d);
-        ct.add(kRaysPrimary);
-
-        int depth = P.max_depth;
-        float ior_1 = 1.0f;
-        bool inside = false;
-        int level = 0;
-        F3 result;
-        while (true) {  // the reflect / refract chain of main.cpp:92-309 (a chain, not a tree: Q3)
-          PT_REGION(1)
-          F3 Pn;
-          Geom g;
-          const int obj = closest_hit<ACCEL, SPILL>(sc, st, ray, Pn, g, ct);
-          PT_REGION(2)
-          if (level == 0 && si == 0 && sj == 0) first_hit = obj;
-          if (obj < 0) {  // main.cpp:144-147
-            result = miss_color(P.sc, P.skybox != 0, ray.d);
-            break;
-          }
-          PT_REGION(9)
-          ct.add(kShadedHits);
-          const uint32_t m = geom_material(g);  // material rows are re-read where used, not carried
-          const F3 intercept = offset_intersection(Pn, get_normal(g, sc.normals, Pn));  // main.cpp:165
-          F3 norm = get_normal(g, sc.normals, intercept);                               // main.cpp:167
-          F3 diff = f3(0, 0, 0), spec = f3(0, 0, 0);
-          PT_REGION(10)
-          if (!inside) {  // main.cpp:172-227
-            for (uint32_t li = 0; li < sc.n_lights; ++li) {
-              // the light index is wave-uniform: read through the scalar cache (s_load), not LDS
-              const float4 l0 = P.sc.lights[2 * li];
-              F3 lpos = xyz(l0);
-              if (AA && P.soft_shadows) {  // main.cpp:180-186 (g++ draws y first)
-                const float jy = rng.rand_float();
-                const float jx = rng.rand_float();
-                lpos = f3(l0.x + P.light_side * (si + jx) / SPP, l0.y + P.light_side * (sj + jy) / SPP, l0.z);
-              }
-              PT_REGION(3)
-              const F3 l_dir = normalized(lpos - intercept);
-              RayS feeler;
-              ray_set(feeler, intercept, l_dir);
-              ct.add(kRaysShadow);
-              PT_REGION(4)
-              const bool shadowed = any_hit<ACCEL, SPILL>(sc, st, feeler, ct);
-              PT_REGION(5)
-              const F3 blinn = normalized((l_dir + get_direction(ray) * -1.0f) / 2);
-              if (!shadowed) {  // main.cpp:222-225: max() and pow() evaluate in double
-                const float4 l1 = P.sc.lights[2 * li + 1];
-                const float4 m0 = sc.mats[4 * m], m1 = sc.mats[4 * m + 1];
-                const float shine = sc.mats[4 * m + 2].x;
-                const float nl = dot(norm, l_dir);
-                const float bn = dot(blinn, norm);
-                const float kd = (0.0f > nl) ? 0.0f : nl;
-                const float kb = (0.0f > bn) ? 0.0f : bn;
-                diff = diff + (xyz(l1) * xyz(m0)) * kd;
-                spec = spec + (xyz(l1) * xyz(m1)) * (float)pow_spec((double)kb, (double)shine);
-              }
-            }
-          }
-          PT_REGION(6)
-          const float4 m2 = sc.mats[4 * m + 2];
-          const float mKd = sc.mats[4 * m].w, mKs = sc.mats[4 * m + 1].w;
-          const F3 col = diff * mKd + spec * mKs;  // main.cpp:232
-          if (depth <= 0) {
-            result = clamp01(col);
-            break;
-          }
-          norm = !inside ? norm : norm * -1.0f;  // main.cpp:238
-          const F3 v = get_direction(ray) * -1.0f;
-          const F3 vn = norm * dot(v, norm);
-          F3 vt = vn - v;
-          bool have_child = false;
-          float weight = 0.0f;
-          RayS child;
-          bool child_inside = inside;
-          float child_ior = ior_1;
-          if (m2.y == 0) {          // opaque: Kr = Ks (main.cpp:250)
-            if (m2.w > 0) {         // reflective (main.cpp:290-300)
-              // g++ evaluates the right operand of `+` first; both calls re-normalise ray.d
-              const F3 b = get_direction(ray);
-              const F3 a = norm * dot(get_direction(ray) * -1.0f, norm) * 2;
-              ray_set(child, intercept, a + b);
-              weight = mKs;
-              have_child = true;
-              ct.add(kRaysReflect);
-            }
-          } else {                  // transmissive (main.cpp:252-283): Kr = 1/2*(Rs+Rp) == 0 (Q3)
-            const float n = !inside ? ior_1 / m2.z : ior_1 / 1;
-            const float sinOt = n * length(vt);
-            const float insqrt = (float)(1 - (double)sinOt * (double)sinOt);  // 1 - pow(sinOt,2) in double
-            if (insqrt >= 0) {
-              const float cosOt = sqrtf(insqrt);
-              F3 refractDir = normalized(vt) * sinOt + norm * (-cosOt);
-              refractDir = normalized(refractDir);
-              ray_set(child, offset_intersection(Pn, refractDir), refractDir);  // main.cpp:267
-              child_ior = !inside ? m2.z : 1.0f;
-              child_inside = !inside;
-              weight = 1.0f;  // (1 - Kr) with Kr == 0; the zero-weight reflection ray is not traced
-              have_child = true;
-              ct.add(kRaysRefract);
-            }
-          }
-          if (!have_child) {
-            result = clamp01(col);
-            break;
-          }
-          P.levels[(size_t)level * P.level_stride + gid] = make_float4(col.x, col.y, col.z, weight);
-          ++level;
-          --depth;
-          ray = child;
-          ior_1 = child_ior;
-          inside = child_inside;
-        }
-        PT_REGION(7)
-        // fold the chain bottom-up with the per-level clamp (main.cpp:305-307, Q4)
-        while (level > 0) {
-          --level;
-          const float4 rec = P.levels[(size_t)level * P.level_stride + gid];
-          result = clamp01(f3(rec.x, rec.y, rec.z) + result * rec.w);
-        }
+#include "whitted_sample.inc"
         color = color + result;
       }
     }
