@@ -244,11 +244,36 @@ __device__ __forceinline__ void make_primary(const RenderParams& P, const DevCam
   }
 }
 
+// Four lanes per pixel (SUB = 4 of pt_kernel and of the anti-aliased whitted_kernel; a wave renders a 4x4-pixel tile).  The samples of a pixel are
+// independent (own RNG stream each) but main.cpp:792-800 adds them up in sample order, and float
+// addition does not commute: the four lanes take the pixel's samples in order from a shared
+// counter, post each finished sample's radiance to a small ring in LDS, and lane 0 of the pixel
+// adds the ring entries to the pixel colour strictly in sample order.  Same samples, same sum,
+// four times more and four times shorter workgroups (DESIGN.md "Tile schedule": the path
+// tracer's frame ends with a tail as long as its last tiles).
+constexpr int kPtRing = 16;  // finished samples a pixel can hold before the oldest one is added
+struct PtPixelShared {       // [..][pixel]: the 16 pixels of the tile are the fastest index (LDS banks)
+  uint32_t next_start[16];   // next sample index to hand out (runs past the last sample: one ticket per finished lane)
+  uint32_t next_add[16];     // next sample index to add to the pixel colour
+  int32_t first_hit[16];
+  float colour[3][16];             // the pixel's running sum (kept here, not in lane 0's registers)
+  uint32_t tag[kPtRing][16];       // sample index + 1 of the radiance in that ring slot
+  float radiance[kPtRing][3][16];
+};
+
+typedef __attribute__((address_space(3))) volatile PtPixelShared LdsPtPixelShared;
+
 // ---------------------------------------------------------------------------
 // Whitted megakernel
 // ---------------------------------------------------------------------------
-template <int ACCEL, bool LDS, bool STATS, bool AA, bool SPILL = !LDS>
+//
+// SUB = 4 (anti-aliased launches with at least four samples per pixel over a scene traversed from L2): four lanes per pixel, as in the path
+// tracer — the samples of a pixel are handed out by ticket, finished samples wait in a ring in LDS and lane 0 of
+// the pixel adds them in sample order (main.cpp:792-800 sums in that order).  An 8x8 tile of 4 x 4 = 16 chained
+// samples per lane was the longest thing in such a frame; now a wave has a 4x4 tile and a quarter of the samples.
+template <int ACCEL, bool LDS, bool STATS, bool AA, bool SPILL = !LDS, int SUB = 1>
 __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_WHITTED_GLOBAL_WAVES) whitted_kernel(const RenderParams P) {
+  static_assert(SUB == 1 || AA, "four lanes per pixel need more than one sample per pixel");
   extern __shared__ float4 smem[];
   uint32_t tx, ty;
   if (!tile_of_block(P, tx, ty)) return;
@@ -258,7 +283,10 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
   stage_scene<LDS>(sc, P, smem);
 
   const uint32_t lane = threadIdx.x;
-  const int c = (int)(tx * 8 + (lane & 7)), r = (int)(ty * 8 + (lane >> 3));
+  constexpr int TP = SUB == 4 ? 4 : 8;              // tile edge in pixels
+  const uint32_t px = SUB == 4 ? lane >> 2 : lane;  // pixel of the tile this lane works for
+  const uint32_t sub = SUB == 4 ? lane & 3u : 0u;
+  const int c = (int)(tx * TP + (px % TP)), r = (int)(ty * TP + (px / TP));
   Counters<STATS> ct;
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
@@ -267,6 +295,15 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
   st.spill_stride = P.level_stride;
   st.sp = 0;
   st.cap = P.stack_cap;
+  // per-pixel sample hand-out state behind the node stack (only allocated for SUB == 4); explicit LDS address space
+  LdsPtPixelShared& shared = *(LdsPtPixelShared*)(smem + P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2);
+  if (SUB == 4 && sub == 0) {
+    shared.next_start[px] = 0;
+    shared.next_add[px] = 0;
+    shared.first_hit[px] = -1;
+    shared.colour[0][px] = 0.0f; shared.colour[1][px] = 0.0f; shared.colour[2][px] = 0.0f;
+    for (int k = 0; k < kPtRing; ++k) shared.tag[k][px] = 0;
+  }
 
   const bool active = c < P.w && r < P.h;
   if (active) {
@@ -275,7 +312,7 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
     const int y = P.y0 + (r / sh) * sh * ss + (r % sh);
     const uint32_t gid = blockIdx.x * kBlock + lane;
     const int SPP = AA ? (int)P.spp_sqrt : 1;
-    ct.add(kPixels);
+    if (sub == 0) ct.add(kPixels);
 
     F3 color = f3(0, 0, 0);
     int first_hit = -1;
@@ -284,10 +321,61 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
 #ifdef P3D_PT_PROFILE
     RegionProf prof; prof.init();
 #endif
-    for (int si = 0; si < SPP; ++si) {
-      for (int sj = 0; sj < SPP; ++sj) {
+    if (SUB == 1) {
+      for (int si = 0; si < SPP; ++si) {
+        for (int sj = 0; sj < SPP; ++sj) {
 #include "whitted_sample.inc"
-        color = color + result;
+          color = color + result;
+        }
+      }
+    } else {
+      // Lanes of one wave wait for each other here (full ring, lane 0 waiting for the last samples of its pixel),
+      // so the loop is wave-uniform — a ballot every lane takes part in decides its end, a waiting lane sits out
+      // the rest of the trip — exactly as in pt_kernel (where a per-lane `continue` got split off as an inner loop).
+      const int n_samples = SPP * SPP;
+      const unsigned long long trips_max = (unsigned long long)n_samples * 2ull + 1024ull;
+      uint32_t trips_left = trips_max > 0xffffffffull ? 0xffffffffu : (uint32_t)trips_max;
+      const uint32_t spp_magic = (uint32_t)((0x100000000ull + (unsigned)SPP - 1) / (unsigned)SPP);
+      bool done = false, holding = false;
+      int s = 0;
+      while (true) {
+        if (trips_left-- == 0) done = true;
+        if (__ballot(!done) == 0) break;
+        if (done) continue;
+        if (sub == 0) {  // add finished samples to the pixel colour, strictly in sample order
+          uint32_t na = shared.next_add[px];
+          if (na < (uint32_t)n_samples && shared.tag[na % kPtRing][px] == na + 1) {
+            F3 sum = f3(shared.colour[0][px], shared.colour[1][px], shared.colour[2][px]);
+            do {
+              const int k = (int)(na % kPtRing);
+              sum = sum + f3(shared.radiance[k][0][px], shared.radiance[k][1][px], shared.radiance[k][2][px]);
+              ++na;
+            } while (na < (uint32_t)n_samples && shared.tag[na % kPtRing][px] == na + 1);
+            shared.colour[0][px] = sum.x; shared.colour[1][px] = sum.y; shared.colour[2][px] = sum.z;
+            shared.next_add[px] = na;
+          }
+        }
+        if (!holding) {
+          s = (int)__hip_atomic_fetch_add(&shared.next_start[px], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          holding = true;
+        }
+        if (s >= n_samples) {  // nothing left to start: finished, except lane 0 while samples remain to be added
+          done = sub != 0 || shared.next_add[px] >= (uint32_t)n_samples;
+          continue;
+        }
+        if ((uint32_t)s >= shared.next_add[px] + kPtRing) continue;  // wait for room in the ring
+        holding = false;
+        const int si = (int)__umulhi((uint32_t)s, spp_magic);  // s / SPP (exact: s * SPP < 2^32, SPP >= 2)
+        const int sj = s - si * SPP;
+#include "whitted_sample.inc"
+        if (s == 0) shared.first_hit[px] = first_hit;
+        const int k = s % kPtRing;
+        shared.radiance[k][0][px] = result.x; shared.radiance[k][1][px] = result.y; shared.radiance[k][2][px] = result.z;
+        shared.tag[k][px] = (uint32_t)s + 1;
+      }
+      if (sub == 0) {
+        color = f3(shared.colour[0][px], shared.colour[1][px], shared.colour[2][px]);
+        first_hit = shared.first_hit[px];
       }
     }
     if (AA) color = color / (float)(SPP * SPP);  // main.cpp:800
@@ -296,18 +384,20 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
     prof.flush();
 #endif
 
-    const size_t k = (size_t)r * P.w + c;
-    if (P.rgb) {
-      P.rgb[3 * k] = color.x; P.rgb[3 * k + 1] = color.y; P.rgb[3 * k + 2] = color.z;
-    }
-    if (P.hit_id) P.hit_id[k] = first_hit;
-    if (P.rgb8) {  // main.cpp:814-820
-      F3 gc = color;
-      if (P.gamma != 1.0f) {
-        const double ig = (double)(1 / P.gamma);
-        gc = f3((float)pow((double)color.x, ig), (float)pow((double)color.y, ig), (float)pow((double)color.z, ig));
+    if (SUB == 1 || sub == 0) {  // SUB == 4: lane 0 of the pixel holds its colour
+      const size_t k = (size_t)r * P.w + c;
+      if (P.rgb) {
+        P.rgb[3 * k] = color.x; P.rgb[3 * k + 1] = color.y; P.rgb[3 * k + 2] = color.z;
       }
-      P.rgb8[3 * k] = u8fromfloat(gc.x); P.rgb8[3 * k + 1] = u8fromfloat(gc.y); P.rgb8[3 * k + 2] = u8fromfloat(gc.z);
+      if (P.hit_id) P.hit_id[k] = first_hit;
+      if (P.rgb8) {  // main.cpp:814-820
+        F3 gc = color;
+        if (P.gamma != 1.0f) {
+          const double ig = (double)(1 / P.gamma);
+          gc = f3((float)pow((double)color.x, ig), (float)pow((double)color.y, ig), (float)pow((double)color.z, ig));
+        }
+        P.rgb8[3 * k] = u8fromfloat(gc.x); P.rgb8[3 * k + 1] = u8fromfloat(gc.y); P.rgb8[3 * k + 2] = u8fromfloat(gc.z);
+      }
     }
   }
   if (STATS) flush_stats<STATS>(ct, P.stats);

@@ -29,6 +29,10 @@ namespace {
 #ifndef P3D_PT_SUB4_MIN_SPP_SQRT
 #define P3D_PT_SUB4_MIN_SPP_SQRT 4
 #endif
+#ifndef P3D_WHITTED_SUB4_MIN_SPP_SQRT
+#define P3D_WHITTED_SUB4_MIN_SPP_SQRT 2
+#endif
+constexpr uint32_t kWhittedSub4MinSppSqrt = P3D_WHITTED_SUB4_MIN_SPP_SQRT;
 constexpr uint32_t kPtSub4MinSppSqrt = P3D_PT_SUB4_MIN_SPP_SQRT;  // from 16 samples per pixel: 4 lanes per pixel
 constexpr uint32_t kLdsSceneLimitBytesPt = 16 * 1024;  // same for the path tracer (not re-tuned: its packaged scenes are 1-2 KB)
 constexpr uint32_t kLdsSceneLimitBytes = 26 * 1024;  // stage the scene in LDS up to this size
@@ -369,6 +373,12 @@ template <int ACCEL, bool LDS, bool STATS>
 hipError_t launch_one(bool pt, bool aa, bool sub4, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
   if (pt && sub4) hipLaunchKernelGGL((pt_kernel<ACCEL, LDS, STATS, 4>), dim3(blocks), dim3(kBlock), lds, st, P);
   else if (pt) hipLaunchKernelGGL((pt_kernel<ACCEL, LDS, STATS, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
+  // anti-aliased, four or more samples per pixel, scene traversed from L2: four lanes per pixel (4x4-pixel
+  // tiles).  Only there: 100k triangles 512x512 2x2 AA 11.17 -> 6.84 ms, but a staged scene pays for one LDS
+  // copy per 16 pixels instead of per 64 (balls_medium 3x3 AA 3.48 -> 5.17 ms, balls_low 2x2 0.60 -> 0.65 ms).
+  else if (aa && sub4 && !LDS) {
+    if constexpr (!LDS) hipLaunchKernelGGL((whitted_kernel<ACCEL, false, STATS, true, true, 4>), dim3(blocks), dim3(kBlock), lds, st, P);
+  }
   // LDS-staged scene whose worst-case stack does not fit LDS: staged scene + spilling stack
   else if (LDS && P.stack_spills && aa) hipLaunchKernelGGL((whitted_kernel<ACCEL, LDS, STATS, true, true>), dim3(blocks), dim3(kBlock), lds, st, P);
   else if (LDS && P.stack_spills) hipLaunchKernelGGL((whitted_kernel<ACCEL, LDS, STATS, false, true>), dim3(blocks), dim3(kBlock), lds, st, P);
@@ -527,7 +537,9 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   P.stack_spills = lds_spill ? 1u : 0u;
   P.lds_scene_f4 = lds_scene ? s->blob_f4 : 0;
   // path tracer with >= 16 samples per pixel: four lanes per pixel, 4x4-pixel tiles (pt_kernel SUB = 4)
-  const bool sub4 = pt && cfg->spp_sqrt >= kPtSub4MinSppSqrt;
+  // ... and anti-aliased Whitted launches with >= 4 samples per pixel over a scene traversed from L2 (whitted_kernel SUB = 4)
+  const bool sub4 = (pt && cfg->spp_sqrt >= kPtSub4MinSppSqrt) ||
+                    (!pt && !lds_scene && cfg->antialiasing && cfg->spp_sqrt >= kWhittedSub4MinSppSqrt);
   const uint32_t tp = sub4 ? 4 : 8;  // tile edge in pixels
   const size_t lds_bytes = (size_t)P.lds_scene_f4 * sizeof(float4) + (size_t)cap * kBlock * sizeof(uint2) +
                            (sub4 ? sizeof(PtPixelShared) : 0);

@@ -64,25 +64,6 @@ struct Pending {
   int n;
 };
 
-// SUB = 4: four lanes per pixel (a wave renders a 4x4-pixel tile).  The samples of a pixel are
-// independent (own RNG stream each) but main.cpp:792-800 adds them up in sample order, and float
-// addition does not commute: the four lanes take the pixel's samples in order from a shared
-// counter, post each finished sample's radiance to a small ring in LDS, and lane 0 of the pixel
-// adds the ring entries to the pixel colour strictly in sample order.  Same samples, same sum,
-// four times more and four times shorter workgroups (DESIGN.md "Tile schedule": the path
-// tracer's frame ends with a tail as long as its last tiles).
-constexpr int kPtRing = 16;  // finished samples a pixel can hold before the oldest one is added
-struct PtPixelShared {       // [..][pixel]: the 16 pixels of the tile are the fastest index (LDS banks)
-  uint32_t next_start[16];   // next sample index to hand out (runs past the last sample: one ticket per finished lane)
-  uint32_t next_add[16];     // next sample index to add to the pixel colour
-  int32_t first_hit[16];
-  float colour[3][16];             // the pixel's running sum (kept here, not in lane 0's registers)
-  uint32_t tag[kPtRing][16];       // sample index + 1 of the radiance in that ring slot
-  float radiance[kPtRing][3][16];
-};
-
-typedef __attribute__((address_space(3))) volatile PtPixelShared LdsPtPixelShared;
-
 template <int ACCEL, bool LDS, bool STATS, int SUB = 1>
 __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderParams P) {
   extern __shared__ float4 smem[];

@@ -297,6 +297,33 @@ def test_device_built_bvh_finds_the_same_closest_hits(scene, legacy, tri5k_path)
     assert not occ_b[(hit_b < 0) & (hit_n < 0) & (hit_e < 0)].any()
 
 
+@pytest.mark.parametrize("kw", [dict(spp_sqrt=2), dict(spp_sqrt=3, soft_shadows=1), dict(spp_sqrt=2, soft_shadows=1, depth_of_field=1, sample_disk=0),
+                                dict(spp_sqrt=5, sample_mode=p3d.SAMPLE_TENT)])
+def test_antialiased_whitted_over_a_scene_traversed_from_l2(kw, tri5k_path):
+    """Anti-aliased Whitted over a scene too big for LDS takes the four-lanes-per-pixel kernel (4x4-pixel tiles,
+    samples handed out by ticket, summed in sample order by lane 0 of the pixel): same bits as the oracle's
+    sequential sample loop, counters included, and invariant under striping / sub-rectangles."""
+    dev, sc = _pair(tri5k_path, res=(96, 80), grid=False)
+    cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, antialiasing=1, seed=11, collect_stats=1, **kw)
+    rgb, hit, st = dev.render(cfg)
+    o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+    compare((rgb, hit), (o_rgb, o_hit), 5e-6)
+    for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "node_tests", "tri_tests", "shaded_hits", "pixels"):
+        assert getattr(st, k) == getattr(o_st, k), k
+    cfg.collect_stats = 0
+    full, full_hit, _ = dev.render(cfg)
+    assert (full.view(np.uint32) == rgb.view(np.uint32)).all()
+    for world, sh in ((2, 8), (4, 4)):
+        out, out_hit = np.zeros_like(full), np.zeros_like(full_hit)
+        for rank in range(world):
+            a, b, _ = dev.render(cfg, tile=p3d.stripe_tile((96, 80), rank, world, sh))
+            rows = p3d.stripe_rows((96, 80), rank, world, sh)
+            out[rows], out_hit[rows] = a, b
+        assert (out.view(np.uint32) == full.view(np.uint32)).all() and (out_hit == full_hit).all()
+    a, _, _ = dev.render(cfg, tile=p3d.Tile(10, 6, 37, 29, 0, 1))
+    assert (a.view(np.uint32) == full[6:35, 10:47].view(np.uint32)).all()
+
+
 @pytest.mark.parametrize("n_objs", [0, 1, 2, 3])
 def test_device_built_bvh_tiny_scenes(n_objs, tmp_path):
     """Degenerate sizes of the GPU builder: no object (no tree), one (the root is a leaf), two and three."""
