@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define P3D_ABI_VERSION 1u
+#define P3D_ABI_VERSION 2u
 
 typedef enum p3d_status {
   P3D_OK = 0,
@@ -182,6 +182,26 @@ typedef struct p3d_scene_desc {
 #define P3D_TILE_ORDER_COST 0u
 #define P3D_TILE_ORDER_FRAME 1u
 
+/*
+ * What becomes of BVH::hit_stack (bvh.cpp:86), which the reference keeps as ONE member for the
+ * whole frame: an any-hit query that returns `true` (bvh.cpp:322) leaves its entries behind, and
+ * they are still there when the NEXT pixel's primary ray is traced (serial pixel loop,
+ * main.cpp:747-751); that closest-hit query drains them (bvh.cpp:256-274), which can re-normalise
+ * its ray copy once more (ray.h:16-18) and move the hit point by an ulp.
+ *   LITERAL (default, 0): every pixel starts with exactly the entries the reference's serial loop
+ *     would hand it (x fastest, rows ascending, samples of a pixel in order).  The GPU renders all
+ *     pixels speculatively on an empty stack, keeps every pixel's leftover, and re-renders the
+ *     pixels whose first closest hit changes under the predecessor's leftover, round by round
+ *     until nothing changes (DESIGN.md "hit_stack hand-off").  Zero-weight reflection rays of
+ *     transmissive materials (Kr = 1/2*(Rs+Rp) = 0, main.cpp:282,290-300) are traced for their
+ *     effect on the stack, as the reference traces them.  Frames are bit-identical to the
+ *     reference's order of execution.  Only Whitted + accel = Bvh have such a stack.
+ *   PER_PIXEL (1): the stack is emptied at every primary sample and zero-weight rays are skipped:
+ *     one launch, no hand-off; hit IDs as LITERAL, colours differ by a few 1e-5 on sphere scenes.
+ */
+#define P3D_STACK_LITERAL 0u
+#define P3D_STACK_PER_PIXEL 1u
+
 typedef struct p3d_config {
   uint32_t integrator;    /* PATHTRACING        constants.h:36  */
   uint32_t accel;         /* acl_str            constants.h:44  */
@@ -200,6 +220,8 @@ typedef struct p3d_config {
   uint32_t tile_order;    /* P3D_TILE_ORDER_*: scheduling only, never changes a result */
   uint64_t seed;          /* replaces set_rand_seed(time*time), main.cpp:722:
                              every (pixel, sample) draws from its own stream */
+  uint32_t stack_mode;    /* P3D_STACK_*: BVH::hit_stack across pixels (bvh.cpp:86) */
+  uint32_t reserved;
 } p3d_config;
 
 /*
@@ -235,6 +257,10 @@ typedef struct p3d_stats {
   uint64_t pixels;
   uint64_t max_stack;    /* deepest traversal stack seen (entries) */
   double kernel_ms;      /* HIP-event time of the kernel(s) of this call */
+  /* P3D_STACK_LITERAL only: the hand-off of BVH::hit_stack from pixel to pixel */
+  uint64_t handoff_checked;  /* pixels whose first closest hit was re-traced on the predecessor's leftover */
+  uint64_t handoff_redone;   /* pixels rendered again because that hit changed */
+  uint64_t handoff_rounds;   /* rounds until no leftover changed any more */
 } p3d_stats;
 
 /* Device-resident scene, one per HIP device.  A p3d_scene also owns per-launch scratch and the
@@ -302,6 +328,16 @@ int p3d_render_tile(p3d_scene* scene, const p3d_config* cfg, const p3d_tile* til
 int p3d_render_tile_device(p3d_scene* scene, const p3d_config* cfg, const p3d_tile* tile,
                            float* d_rgb, int32_t* d_hit_id, uint8_t* d_rgb8,
                            void* hip_stream, p3d_stats* stats);
+
+/*
+ * Errors a kernel detects while it runs (a hit_stack leftover that outgrew its record, a sample hand-out loop that
+ * reached its trip bound and would write pixels with samples missing) raise a flag on the device.  The host-buffer
+ * call and every call with `stats` turn it into P3D_ERR_CAPACITY themselves; after device-buffer calls without
+ * `stats` ask here: waits for the scene's device, returns P3D_OK or P3D_ERR_CAPACITY and clears the flag.
+ */
+int p3d_scene_status(p3d_scene* scene);
+/* Test hook: trip bound of the four-lanes-per-pixel sample loops (0 = the real bound), process-wide. */
+int p3d_debug_set_trip_bound(uint32_t trips);
 
 /*
  * Batched traversal queries — device counterparts of BVH::intersect_bvh

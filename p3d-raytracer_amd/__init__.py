@@ -23,12 +23,14 @@ LIB_PATH = os.environ.get("P3D_LIB") or os.path.join(HERE, "libp3d.so")  # P3D_L
 ACCEL_NONE, ACCEL_GRID, ACCEL_BVH = 0, 1, 2
 WHITTED, PATHTRACE = 0, 1
 TILE_ORDER_COST, TILE_ORDER_FRAME = 0, 1
+STACK_LITERAL, STACK_PER_PIXEL = 0, 1
 SAMPLE_JITTER, SAMPLE_TENT = 0, 1
 LOAD_LEGACY_F11 = 1
 
 EXPORTS = [
     "p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_config_default",
     "p3d_scene_create", "p3d_scene_create_device_bvh", "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_render_tile", "p3d_render_tile_device",
+    "p3d_scene_status", "p3d_debug_set_trip_bound",
     "p3d_trace_closest", "p3d_trace_any", "p3d_host_scene_load", "p3d_host_scene_destroy",
     "p3d_host_scene_set_resolution", "p3d_host_scene_set_lens", "p3d_host_scene_replicate_lights",
     "p3d_host_scene_desc",
@@ -90,7 +92,8 @@ class Config(C.Structure):
                 ("spp_sqrt", C.c_uint32), ("antialiasing", C.c_uint32), ("depth_of_field", C.c_uint32),
                 ("sample_disk", C.c_uint32), ("soft_shadows", C.c_uint32), ("sample_mode", C.c_uint32),
                 ("light_side", C.c_float), ("gamma", C.c_float), ("collect_stats", C.c_uint32),
-                ("skybox", C.c_uint32), ("tile_order", C.c_uint32), ("seed", C.c_uint64)]
+                ("skybox", C.c_uint32), ("tile_order", C.c_uint32), ("seed", C.c_uint64),
+                ("stack_mode", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class SkyboxFace(C.Structure):
@@ -111,7 +114,8 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "rays_bounce", "rays_light",
         "node_tests", "sphere_tests", "tri_tests", "box_tests", "plane_tests", "shaded_hits", "pixels",
-        "max_stack")] + [("kernel_ms", C.c_double)]
+        "max_stack")] + [("kernel_ms", C.c_double)] + [(n, C.c_uint64) for n in (
+        "handoff_checked", "handoff_redone", "handoff_rounds")]
 
     @property
     def rays(self):

@@ -418,13 +418,17 @@ __device__ __forceinline__ bool pop_closer(Stack& st, float tmin, uint32_t& desc
 
 // Closest hit.  `ray` is the traversal's private copy (bvh.cpp:198 takes Ray by value).
 // Returns the leaf slot of the hit (-1 = miss) and the hit point d*tmin + o (bvh.cpp:271).
+// *root_passed (optional): the ray got past the root test of bvh.cpp:203-205, i.e. the query touched hit_stack
+// and left it empty; a ray that fails it returns with the stack exactly as it found it.
 template <bool SPILL, class CT>
-__device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_point, Geom& hit_geom, CT& ct) {
+__device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_point, Geom& hit_geom, CT& ct,
+                           bool* root_passed = nullptr) {
   float tmp, tmin = FLT_MAX;
   int hit = -1;
   const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
   if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, false)) return -1;  // stale entries stay (Q2)
+  if (root_passed) *root_passed = true;
   uint32_t desc = __float_as_uint(root.lo.w);
   bool walking = true;
   while (walking) {
@@ -666,9 +670,10 @@ __device__ bool grid_any(const DevScene& sc, RayS& ray, CT& ct) {
 // traversal's hit point otherwise.
 // ---------------------------------------------------------------------------
 template <int ACCEL, bool SPILL, class CT>
-__device__ __forceinline__ int closest_hit(const DevScene& sc, Stack& st, RayS& ray, F3& P, Geom& g, CT& ct) {
+__device__ __forceinline__ int closest_hit(const DevScene& sc, Stack& st, RayS& ray, F3& P, Geom& g, CT& ct,
+                                           bool* root_passed = nullptr) {
   if (ACCEL == P3D_ACCEL_BVH) {
-    const int slot = bvh_closest<SPILL>(sc, st, ray, P, g, ct);
+    const int slot = bvh_closest<SPILL>(sc, st, ray, P, g, ct, root_passed);
     return slot < 0 ? -1 : (int)geom_object(g);
   } else if (ACCEL == P3D_ACCEL_GRID) {
     return grid_closest(sc, ray, P, g, ct);

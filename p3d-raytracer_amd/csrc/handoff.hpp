@@ -1,0 +1,127 @@
+// handoff.hpp — the reference's ONE BVH::hit_stack for the whole frame (bvh.cpp:86), reproduced on a GPU.
+//
+// The reference renders pixels one after the other (main.cpp:747-751) and its any-hit query leaves entries on
+// the member stack whenever it returns `true` (bvh.cpp:322).  The next closest-hit query that gets past the
+// root test pops them AFTER its own entries (bvh.cpp:256-265: LIFO) and visits those that are nearer than its
+// hit — which can re-normalise its ray copy once more (ray.h:16-18) and move the hit point by an ulp.  So the
+// colour of pixel p depends on what the last pixel before it that touched the stack left behind.
+//
+// What the kernels do (P3D_STACK_LITERAL, DESIGN.md "hit_stack hand-off"):
+//   pass 1   every pixel ("unit") is rendered on an EMPTY stack; it records its leftover, whether it touched the
+//            stack at all (a primary ray that fails the root test, bvh.cpp:203-205, passes its predecessor's
+//            leftover on unchanged) and the result of its first closest hit (hit point + object).
+//   check    every unit whose predecessor left something re-traces that first closest hit on the predecessor's
+//            leftover.  Everything a pixel computes after that query depends on the stack only through the query's
+//            result, so an unchanged result means an unchanged pixel.
+//   redo     the units whose result changed are rendered again, seeded; if a unit's own leftover changes, its
+//            successor is looked at in the next round (check + redo again), until no leftover changes: a fixed
+//            point of "every unit was rendered on its predecessor's current leftover" is the serial result,
+//            because the first unit's stack is empty in both and each next one is determined by the one before.
+// Units are numbered in the reference's order: tile row by tile row, x ascending; every row has `halo` extra slots
+// in front for the chain of pixels that precedes the row in the FRAME when the row above it in the tile is not
+// its predecessor there (stripes of a multi-GPU frame, sub-rectangles): see halo_find_kernel.
+#pragma once
+
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+namespace p3d {
+
+constexpr uint32_t kHaloChain = 8;        // frame pixels rendered in front of a row that starts a chain of its own
+constexpr uint32_t kMetaTouched = 1u << 17;
+constexpr uint32_t kNoUnit = 0xffffffffu;
+
+enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoError, kHoListA, kHoListB, kHoListC, kHoNumCounters };
+constexpr uint32_t kHoErrLeftoverCap = 1u;   // a leftover had more entries than a slot holds
+constexpr uint32_t kHoErrNoFixedPoint = 2u;  // round bound reached
+constexpr uint32_t kHoErrTrips = 4u;         // sample hand-out loop hit its trip bound (SUB = 4 kernels)
+
+struct Handoff {
+  uint32_t n_units;     // rows * row_units
+  uint32_t row_units;   // halo + tile width
+  uint32_t halo;        // 0 or kHaloChain
+  uint32_t rows;        // tile rows
+  uint32_t cap;         // entries per leftover slot
+  uint32_t persistent;  // list kernel: one workgroup, loop over rounds until the list stays empty
+  uint32_t list_cap;
+  uint32_t max_rounds;
+  uint2* entries;          // [2][cap][n_units]  leftover stacks, two slots per unit
+  uint32_t* meta;          // [n_units] bits 0..15 entries of the current slot, bit 16 which slot, bit 17 touched
+  float4* first;           // [n_units] {hit point, object id} of the first closest hit of the first touching sample
+  uint32_t* first_sample;  // [n_units] index of that sample (anti-aliased launches)
+  uint32_t* touched;       // bit per unit
+  const uint8_t* row_chain;  // [rows] row starts a chain of its own; null: one chain through the whole tile
+  const uint32_t* halo_pix;  // [rows * halo] frame pixel (y * res_x + x) of a halo slot, kNoUnit: none
+  uint4* list_in;            // work of this launch {unit, predecessor, predecessor's slot << 16 | entries, 1 = check first}
+  uint4* list_out;           // units to look at in the next round
+  uint32_t* n_in;
+  uint32_t* n_out;
+  uint32_t* counters;        // kHoNumCounters words
+};
+
+// highest set bit in [lo, i), -1: none
+__device__ inline int find_prev_bit(const uint32_t* bits, uint32_t lo, uint32_t i) {
+  if (i <= lo) return -1;
+  uint32_t w = (i - 1) >> 5;
+  const uint32_t wlo = lo >> 5;
+  uint32_t word = bits[w] & (0xffffffffu >> (31u - ((i - 1) & 31u)));
+  while (true) {
+    if (w == wlo) word &= 0xffffffffu << (lo & 31u);
+    if (word) return (int)(w * 32u + 31u - (uint32_t)__clz((int)word));
+    if (w == wlo) return -1;
+    --w;
+    word = bits[w];
+  }
+}
+// lowest set bit in [i, hi), -1: none
+__device__ inline int find_next_bit(const uint32_t* bits, uint32_t i, uint32_t hi) {
+  if (i >= hi) return -1;
+  uint32_t w = i >> 5;
+  const uint32_t whi = (hi - 1) >> 5;
+  uint32_t word = bits[w] & (0xffffffffu << (i & 31u));
+  while (true) {
+    if (w == whi) word &= 0xffffffffu >> (31u - ((hi - 1) & 31u));
+    if (word) return (int)(w * 32u + (uint32_t)__ffs((int)word) - 1u);
+    if (w == whi) return -1;
+    ++w;
+    word = bits[w];
+  }
+}
+
+// the unit whose leftover `u` starts on: the last unit before it that touched the stack (-1: u starts empty)
+__device__ inline int handoff_pred(const Handoff& H, uint32_t u) {
+  if (!H.row_chain) return find_prev_bit(H.touched, 0, u);
+  uint32_t row = u / H.row_units, i = u;
+  while (true) {
+    const uint32_t lo = row * H.row_units;
+    const int b = find_prev_bit(H.touched, lo, i);
+    if (b >= 0) return b;
+    if (H.row_chain[row] || row == 0) return -1;
+    i = lo;
+    --row;
+  }
+}
+// the unit that starts on u's leftover (-1: nobody in this tile does)
+__device__ inline int handoff_succ(const Handoff& H, uint32_t u) {
+  if (!H.row_chain) return find_next_bit(H.touched, u + 1, H.n_units);
+  uint32_t row = u / H.row_units, i = u + 1;
+  while (true) {
+    const uint32_t hi = (row + 1) * H.row_units;
+    const int b = find_next_bit(H.touched, i, hi);
+    if (b >= 0) return b;
+    ++row;
+    if (row >= H.rows || H.row_chain[row]) return -1;
+    i = hi;
+  }
+}
+
+__device__ __forceinline__ bool handoff_touched(const Handoff& H, uint32_t u) { return (H.touched[u >> 5] >> (u & 31u)) & 1u; }
+
+__device__ __forceinline__ void handoff_append(uint4* list, uint32_t* n, uint32_t cap, uint32_t* counters, uint4 e) {
+  const uint32_t i = atomicAdd(n, 1u);
+  if (i < cap) list[i] = e;
+  else atomicOr(&counters[kHoError], kHoErrLeftoverCap);
+}
+
+}  // namespace p3d

@@ -12,6 +12,7 @@
 #pragma once
 
 #include "device_core.hpp"
+#include "handoff.hpp"
 #include "p3d.h"
 
 // minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ arg)
@@ -99,6 +100,13 @@ struct RenderParams {
   const uint32_t* sched;
   uint32_t* tile_cost;
   uint32_t stack_spills;  // LDS-staged scene with the spilling stack (host-side kernel choice)
+  // P3D_STACK_LITERAL (handoff.hpp)
+  Handoff hand;
+  int32_t row0;            // first tile row of this launch (units are numbered over the whole tile)
+  uint32_t tile_blocks;    // workgroups that render tiles; the ones behind them render halo chains (pass 1, check)
+  float4* deferred;        // zero-weight reflection rays put aside, 2 x float4 each, [2 * entry][thread]
+  uint32_t* status;        // device-detected errors of this scene (kHoErr* bits), never cleared by a kernel
+  uint32_t debug_trip_bound;  // tests only: trip bound of the four-lanes-per-pixel sample loops (0 = the real bound)
 };
 
 // LDS map of one workgroup:  [ staged scene (lds_scene_f4 float4) | node stack (cap * 64 * 8 B) | per-pixel sample ring (PT, 4 lanes per pixel) ]
@@ -263,6 +271,76 @@ struct PtPixelShared {       // [..][pixel]: the 16 pixels of the tile are the f
 
 typedef __attribute__((address_space(3))) volatile PtPixelShared LdsPtPixelShared;
 
+// Where a unit of the hand-off (handoff.hpp) lies in the image: tile pixels and, in front of every row, the halo slots.
+struct UnitPlace {
+  int c, r, x, y;  // tile column / tile row (output index), image pixel
+  bool halo;       // a frame pixel rendered only for what it leaves on the stack: no output
+  bool valid;
+};
+__device__ __forceinline__ int image_row(const RenderParams& P, int r) {
+  const int sh = P.stripe_h > 0 ? P.stripe_h : 1, ss = P.stripe_h > 0 ? P.stripe_stride : 1;
+  return P.y0 + (r / sh) * sh * ss + (r % sh);
+}
+__device__ __forceinline__ UnitPlace place_of_unit(const RenderParams& P, uint32_t unit) {
+  const Handoff& H = P.hand;
+  UnitPlace u;
+  const uint32_t row = unit / H.row_units, j = unit - row * H.row_units;
+  u.r = (int)row - P.row0;
+  u.halo = j < H.halo;
+  u.valid = true;
+  if (u.halo) {
+    const uint32_t fp = H.halo_pix[row * H.halo + j];
+    u.valid = fp != kNoUnit;
+    u.c = 0;
+    u.x = (int)(fp % (uint32_t)P.sc.cam.res_x);
+    u.y = (int)(fp / (uint32_t)P.sc.cam.res_x);
+  } else {
+    u.c = (int)(j - H.halo);
+    u.x = P.x0 + u.c;
+    u.y = image_row(P, u.r);
+  }
+  return u;
+}
+// pass 1 / check: the unit of a lane of a halo workgroup (8 chains of kHaloChain slots per wave)
+__device__ __forceinline__ bool halo_unit_of_lane(const RenderParams& P, uint32_t lane, uint32_t& unit) {
+  const Handoff& H = P.hand;
+  const uint32_t slot = (blockIdx.x - P.tile_blocks) * kBlock + lane;
+  const uint32_t row = slot / kHaloChain, j = slot % kHaloChain;
+  if (H.halo == 0 || row >= H.rows || !H.row_chain[row]) return false;
+  unit = row * H.row_units + j;
+  return H.halo_pix[row * H.halo + j] != kNoUnit;
+}
+
+template <bool SPILL, class CT>
+__device__ __forceinline__ void seed_stack(Stack& st, const Handoff& H, uint32_t pred, uint32_t slot_count, CT& ct) {
+  st.sp = 0;
+  const uint32_t n = slot_count & 0xffffu, slot = slot_count >> 16;
+  for (uint32_t e = 0; e < n; ++e) {
+    const uint2 v = H.entries[((size_t)slot * H.cap + e) * H.n_units + pred];
+    push<SPILL>(st, v.x, __uint_as_float(v.y), ct);
+  }
+}
+__device__ __forceinline__ bool same_first(float4 a, float4 b) {
+  return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
+         __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
+}
+// The first closest hit of a unit's first touching sample, traced on whatever the stack holds (bvh.cpp:198-276).
+template <bool SPILL, class CT>
+__device__ __forceinline__ float4 first_closest_hit(const RenderParams& P, const DevScene& sc, Stack& st, int x, int y, uint32_t sample, CT& ct) {
+  Rng rng;
+  rng.state = 0; rng.inc = 1;
+  const int SPP = P.antialiasing ? (int)P.spp_sqrt : 1;
+  const int si = (int)sample / SPP, sj = (int)sample % SPP;
+  if (P.antialiasing) rng.seed_stream(P.seed, (uint32_t)(y * sc.cam.res_x + x), sample);
+  F3 o, d, Pn;
+  make_primary(P, sc.cam, x, y, si, sj, rng, o, d);
+  RayS ray;
+  ray_set(ray, o, d);
+  Geom g;
+  const int obj = closest_hit<P3D_ACCEL_BVH, SPILL>(sc, st, ray, Pn, g, ct);
+  return obj < 0 ? make_float4(0.f, 0.f, 0.f, __int_as_float(-1)) : make_float4(Pn.x, Pn.y, Pn.z, __int_as_float(obj));
+}
+
 // ---------------------------------------------------------------------------
 // Whitted megakernel
 // ---------------------------------------------------------------------------
@@ -271,14 +349,26 @@ typedef __attribute__((address_space(3))) volatile PtPixelShared LdsPtPixelShare
 // tracer — the samples of a pixel are handed out by ticket, finished samples wait in a ring in LDS and lane 0 of
 // the pixel adds them in sample order (main.cpp:792-800 sums in that order).  An 8x8 tile of 4 x 4 = 16 chained
 // samples per lane was the longest thing in such a frame; now a wave has a 4x4 tile and a quarter of the samples.
-template <int ACCEL, bool LDS, bool STATS, bool AA, bool SPILL = !LDS, int SUB = 1>
-__global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_WHITTED_GLOBAL_WAVES) whitted_kernel(const RenderParams P) {
+//
+// LIT (P3D_STACK_LITERAL, handoff.hpp): 0 = the stack is emptied at every primary sample (one launch, nothing kept);
+// 1 = pass 1: the pixel starts on an empty stack, the samples of the pixel hand the stack on, and the pixel's leftover,
+// its touched flag and its first closest hit are recorded; 2 = the lanes take units from a work list, seed the stack
+// with the predecessor's leftover, re-trace the first closest hit if the list entry asks for it, and render the unit again
+// if that hit changed.
+template <int ACCEL, bool LDS, bool STATS, bool AA, bool SPILL = !LDS, int SUB = 1, int LIT = 0>
+__global__ void __launch_bounds__(kBlock, (LDS || AA || LIT == 2) ? P3D_WHITTED_WAVES : P3D_WHITTED_GLOBAL_WAVES) whitted_kernel(const RenderParams P) {
   static_assert(SUB == 1 || AA, "four lanes per pixel need more than one sample per pixel");
+  static_assert(LIT == 0 || (ACCEL == P3D_ACCEL_BVH && SUB == 1), "only the BVH has a stack to hand on; one lane per pixel");
   extern __shared__ float4 smem[];
-  uint32_t tx, ty;
-  if (!tile_of_block(P, tx, ty)) return;
+  uint32_t tx = 0, ty = 0;
+  const bool halo_block = LIT == 1 && blockIdx.x >= P.tile_blocks;
+  if (LIT != 2 && !halo_block && !tile_of_block(P, tx, ty)) return;
+  if (LIT == 2) {  // nothing on the list for this workgroup: leave before the scene is staged
+    const uint32_t n0 = __hip_atomic_load(P.hand.n_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((size_t)blockIdx.x * kBlock >= (n0 > P.hand.list_cap ? P.hand.list_cap : n0)) return;
+  }
   P3D_TL_BEGIN()
-  const unsigned long long t_begin = P.tile_cost ? wall_clock64() : 0;
+  const unsigned long long t_begin = (LIT != 2 && P.tile_cost) ? wall_clock64() : 0;
   DevScene sc = P.sc;
   stage_scene<LDS>(sc, P, smem);
 
@@ -286,7 +376,6 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
   constexpr int TP = SUB == 4 ? 4 : 8;              // tile edge in pixels
   const uint32_t px = SUB == 4 ? lane >> 2 : lane;  // pixel of the tile this lane works for
   const uint32_t sub = SUB == 4 ? lane & 3u : 0u;
-  const int c = (int)(tx * TP + (px % TP)), r = (int)(ty * TP + (px / TP));
   Counters<STATS> ct;
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
@@ -295,6 +384,7 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
   st.spill_stride = P.level_stride;
   st.sp = 0;
   st.cap = P.stack_cap;
+  const uint32_t gid = blockIdx.x * kBlock + lane;
   // per-pixel sample hand-out state behind the node stack (only allocated for SUB == 4); explicit LDS address space
   LdsPtPixelShared& shared = *(LdsPtPixelShared*)(smem + P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2);
   if (SUB == 4 && sub == 0) {
@@ -305,104 +395,253 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA) ? P3D_WHITTED_WAVES : P3D_
     for (int k = 0; k < kPtRing; ++k) shared.tag[k][px] = 0;
   }
 
-  const bool active = c < P.w && r < P.h;
-  if (active) {
-    const int sh = P.stripe_h > 0 ? P.stripe_h : 1, ss = P.stripe_h > 0 ? P.stripe_stride : 1;
-    const int x = P.x0 + c;
-    const int y = P.y0 + (r / sh) * sh * ss + (r % sh);
-    const uint32_t gid = blockIdx.x * kBlock + lane;
-    const int SPP = AA ? (int)P.spp_sqrt : 1;
-    if (sub == 0) ct.add(kPixels);
-
-    F3 color = f3(0, 0, 0);
-    int first_hit = -1;
-    Rng rng;
-    rng.state = 0; rng.inc = 1;
-#ifdef P3D_PT_PROFILE
-    RegionProf prof; prof.init();
-#endif
-    if (SUB == 1) {
-      for (int si = 0; si < SPP; ++si) {
-        for (int sj = 0; sj < SPP; ++sj) {
-#include "whitted_sample.inc"
-          color = color + result;
-        }
+  const Handoff& H = P.hand;
+  uint4* list_in = H.list_in;
+  uint4* list_out = H.list_out;
+  uint32_t* n_in_p = H.n_in;
+  uint32_t* n_out_p = H.n_out;
+  for (uint32_t round = 0;; ++round) {  // LIT == 2 in one persistent workgroup: a trip per round; otherwise one trip
+    uint32_t n_in = 0;
+    if (LIT == 2) {
+      n_in = __hip_atomic_load(n_in_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      n_in = n_in > H.list_cap ? H.list_cap : n_in;
+      if (n_in == 0) break;
+      if (H.persistent && round >= H.max_rounds) {
+        if (lane == 0) atomicOr(&H.counters[kHoError], kHoErrNoFixedPoint);
+        break;
       }
-    } else {
-      // Lanes of one wave wait for each other here (full ring, lane 0 waiting for the last samples of its pixel),
-      // so the loop is wave-uniform — a ballot every lane takes part in decides its end, a waiting lane sits out
-      // the rest of the trip — exactly as in pt_kernel (where a per-lane `continue` got split off as an inner loop).
-      const int n_samples = SPP * SPP;
-      const unsigned long long trips_max = (unsigned long long)n_samples * 2ull + 1024ull;
-      uint32_t trips_left = trips_max > 0xffffffffull ? 0xffffffffu : (uint32_t)trips_max;
-      const uint32_t spp_magic = (uint32_t)((0x100000000ull + (unsigned)SPP - 1) / (unsigned)SPP);
-      bool done = false, holding = false;
-      int s = 0;
-      while (true) {
-        if (trips_left-- == 0) done = true;
-        if (__ballot(!done) == 0) break;
-        if (done) continue;
-        if (sub == 0) {  // add finished samples to the pixel colour, strictly in sample order
-          uint32_t na = shared.next_add[px];
-          if (na < (uint32_t)n_samples && shared.tag[na % kPtRing][px] == na + 1) {
-            F3 sum = f3(shared.colour[0][px], shared.colour[1][px], shared.colour[2][px]);
-            do {
-              const int k = (int)(na % kPtRing);
-              sum = sum + f3(shared.radiance[k][0][px], shared.radiance[k][1][px], shared.radiance[k][2][px]);
-              ++na;
-            } while (na < (uint32_t)n_samples && shared.tag[na % kPtRing][px] == na + 1);
-            shared.colour[0][px] = sum.x; shared.colour[1][px] = sum.y; shared.colour[2][px] = sum.z;
-            shared.next_add[px] = na;
+      if (blockIdx.x == 0 && lane == 0) atomicAdd(&H.counters[kHoRounds], 1u);
+    }
+    for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {  // LIT == 2: 64 list entries per trip
+      bool active;
+      UnitPlace up;
+      uint32_t unit = 0, pred = 0, pred_slot_count = 0, flags = 0;
+      if (LIT == 2) {
+        if ((size_t)chunk * kBlock >= n_in) break;
+        const uint32_t i = chunk * kBlock + lane;
+        active = i < n_in;
+        up.c = up.r = up.x = up.y = 0; up.halo = false; up.valid = false;
+        if (active) {
+          const uint32_t* e = reinterpret_cast<const uint32_t*>(list_in + i);
+          unit = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pred = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          pred_slot_count = __hip_atomic_load(e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          flags = __hip_atomic_load(e + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          up = place_of_unit(P, unit);
+          active = up.valid;
+        }
+      } else if (halo_block) {
+        active = halo_unit_of_lane(P, lane, unit);
+        up.c = up.r = up.x = up.y = 0; up.halo = true; up.valid = active;
+        if (active) up = place_of_unit(P, unit);
+      } else {
+        up.c = (int)(tx * TP + (px % TP));
+        up.r = (int)(ty * TP + (px / TP));
+        up.halo = false;
+        active = up.c < P.w && up.r < P.h;
+        up.valid = active;
+        up.x = P.x0 + up.c;
+        up.y = image_row(P, up.r);
+        if (LIT == 1) unit = (uint32_t)(P.row0 + up.r) * H.row_units + H.halo + (uint32_t)up.c;
+      }
+
+      bool unit_touched = false;
+      float4 unit_first = make_float4(0.f, 0.f, 0.f, 0.f);
+      uint32_t unit_first_sample = 0;
+      if (LIT == 2 && active) {  // seed with the predecessor's leftover; re-trace the first closest hit if asked to
+        seed_stack<SPILL>(st, H, pred, pred_slot_count, ct);
+        if (flags & 1u) {
+          atomicAdd(&H.counters[kHoChecked], 1u);
+          const float4 now = first_closest_hit<SPILL>(P, sc, st, up.x, up.y, AA ? H.first_sample[unit] : 0u, ct);
+          if (same_first(now, H.first[unit])) active = false;  // nothing this unit computes can differ
+          else seed_stack<SPILL>(st, H, pred, pred_slot_count, ct);
+        }
+        if (active) atomicAdd(&H.counters[kHoRedone], 1u);
+      }
+      if (LIT == 1) st.sp = 0;
+
+      if (active) {
+        const int c = up.c, r = up.r, x = up.x, y = up.y;
+        const int SPP = AA ? (int)P.spp_sqrt : 1;
+        if (sub == 0 && !(LIT != 0 && up.halo)) ct.add(kPixels);
+
+        F3 color = f3(0, 0, 0);
+        int first_hit = -1;
+        Rng rng;
+        rng.state = 0; rng.inc = 1;
+#ifdef P3D_PT_PROFILE
+        RegionProf prof; prof.init();
+#endif
+        if (SUB == 1) {
+          for (int si = 0; si < SPP; ++si) {
+            for (int sj = 0; sj < SPP; ++sj) {
+#include "whitted_sample.inc"
+              color = color + result;
+            }
+          }
+        } else {
+          // Lanes of one wave wait for each other here (full ring, lane 0 waiting for the last samples of its pixel),
+          // so the loop is wave-uniform — a ballot every lane takes part in decides its end, a waiting lane sits out
+          // the rest of the trip — exactly as in pt_kernel (where a per-lane `continue` got split off as an inner loop).
+          const int n_samples = SPP * SPP;
+          const unsigned long long trips_max = P.debug_trip_bound ? (unsigned long long)P.debug_trip_bound : (unsigned long long)n_samples * 2ull + 1024ull;
+          uint32_t trips_left = trips_max > 0xffffffffull ? 0xffffffffu : (uint32_t)trips_max;
+          const uint32_t spp_magic = (uint32_t)((0x100000000ull + (unsigned)SPP - 1) / (unsigned)SPP);
+          bool done = false, holding = false;
+          int s = 0;
+          while (true) {
+            if (trips_left-- == 0) {  // backstop: the pixel would be written with samples missing -> the call fails
+              if (!done) atomicOr(P.status, kHoErrTrips);
+              done = true;
+            }
+            if (__ballot(!done) == 0) break;
+            if (done) continue;
+            if (sub == 0) {  // add finished samples to the pixel colour, strictly in sample order
+              uint32_t na = shared.next_add[px];
+              if (na < (uint32_t)n_samples && shared.tag[na % kPtRing][px] == na + 1) {
+                F3 sum = f3(shared.colour[0][px], shared.colour[1][px], shared.colour[2][px]);
+                do {
+                  const int k = (int)(na % kPtRing);
+                  sum = sum + f3(shared.radiance[k][0][px], shared.radiance[k][1][px], shared.radiance[k][2][px]);
+                  ++na;
+                } while (na < (uint32_t)n_samples && shared.tag[na % kPtRing][px] == na + 1);
+                shared.colour[0][px] = sum.x; shared.colour[1][px] = sum.y; shared.colour[2][px] = sum.z;
+                shared.next_add[px] = na;
+              }
+            }
+            if (!holding) {
+              s = (int)__hip_atomic_fetch_add(&shared.next_start[px], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              holding = true;
+            }
+            if (s >= n_samples) {  // nothing left to start: finished, except lane 0 while samples remain to be added
+              done = sub != 0 || shared.next_add[px] >= (uint32_t)n_samples;
+              continue;
+            }
+            if ((uint32_t)s >= shared.next_add[px] + kPtRing) continue;  // wait for room in the ring
+            holding = false;
+            const int si = (int)__umulhi((uint32_t)s, spp_magic);  // s / SPP (exact: s * SPP < 2^32, SPP >= 2)
+            const int sj = s - si * SPP;
+#include "whitted_sample.inc"
+            if (s == 0) shared.first_hit[px] = first_hit;
+            const int k = s % kPtRing;
+            shared.radiance[k][0][px] = result.x; shared.radiance[k][1][px] = result.y; shared.radiance[k][2][px] = result.z;
+            shared.tag[k][px] = (uint32_t)s + 1;
+          }
+          if (sub == 0) {
+            color = f3(shared.colour[0][px], shared.colour[1][px], shared.colour[2][px]);
+            first_hit = shared.first_hit[px];
           }
         }
-        if (!holding) {
-          s = (int)__hip_atomic_fetch_add(&shared.next_start[px], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          holding = true;
-        }
-        if (s >= n_samples) {  // nothing left to start: finished, except lane 0 while samples remain to be added
-          done = sub != 0 || shared.next_add[px] >= (uint32_t)n_samples;
-          continue;
-        }
-        if ((uint32_t)s >= shared.next_add[px] + kPtRing) continue;  // wait for room in the ring
-        holding = false;
-        const int si = (int)__umulhi((uint32_t)s, spp_magic);  // s / SPP (exact: s * SPP < 2^32, SPP >= 2)
-        const int sj = s - si * SPP;
-#include "whitted_sample.inc"
-        if (s == 0) shared.first_hit[px] = first_hit;
-        const int k = s % kPtRing;
-        shared.radiance[k][0][px] = result.x; shared.radiance[k][1][px] = result.y; shared.radiance[k][2][px] = result.z;
-        shared.tag[k][px] = (uint32_t)s + 1;
-      }
-      if (sub == 0) {
-        color = f3(shared.colour[0][px], shared.colour[1][px], shared.colour[2][px]);
-        first_hit = shared.first_hit[px];
-      }
-    }
-    if (AA) color = color / (float)(SPP * SPP);  // main.cpp:800
+        if (AA) color = color / (float)(SPP * SPP);  // main.cpp:800
 #ifdef P3D_PT_PROFILE
-    PT_REGION(8)
-    prof.flush();
+        PT_REGION(8)
+        prof.flush();
 #endif
 
-    if (SUB == 1 || sub == 0) {  // SUB == 4: lane 0 of the pixel holds its colour
-      const size_t k = (size_t)r * P.w + c;
-      if (P.rgb) {
-        P.rgb[3 * k] = color.x; P.rgb[3 * k + 1] = color.y; P.rgb[3 * k + 2] = color.z;
-      }
-      if (P.hit_id) P.hit_id[k] = first_hit;
-      if (P.rgb8) {  // main.cpp:814-820
-        F3 gc = color;
-        if (P.gamma != 1.0f) {
-          const double ig = (double)(1 / P.gamma);
-          gc = f3((float)pow((double)color.x, ig), (float)pow((double)color.y, ig), (float)pow((double)color.z, ig));
+        if ((SUB == 1 || sub == 0) && !(LIT != 0 && up.halo)) {  // SUB == 4: lane 0 of the pixel holds its colour
+          const size_t k = (size_t)r * P.w + c;
+          if (P.rgb) {
+            P.rgb[3 * k] = color.x; P.rgb[3 * k + 1] = color.y; P.rgb[3 * k + 2] = color.z;
+          }
+          if (P.hit_id) P.hit_id[k] = first_hit;
+          if (P.rgb8) {  // main.cpp:814-820
+            F3 gc = color;
+            if (P.gamma != 1.0f) {
+              const double ig = (double)(1 / P.gamma);
+              gc = f3((float)pow((double)color.x, ig), (float)pow((double)color.y, ig), (float)pow((double)color.z, ig));
+            }
+            P.rgb8[3 * k] = u8fromfloat(gc.x); P.rgb8[3 * k + 1] = u8fromfloat(gc.y); P.rgb8[3 * k + 2] = u8fromfloat(gc.z);
+          }
         }
-        P.rgb8[3 * k] = u8fromfloat(gc.x); P.rgb8[3 * k + 1] = u8fromfloat(gc.y); P.rgb8[3 * k + 2] = u8fromfloat(gc.z);
+
+        if (LIT == 1) {  // what this unit leaves behind (slot 0), whether it touched the stack, its first closest hit
+          uint32_t meta = 0;
+          if (unit_touched) {
+            uint32_t n = (uint32_t)st.sp;
+            if (n > H.cap) { atomicOr(P.status, kHoErrLeftoverCap); n = H.cap; }
+            for (uint32_t e = 0; e < n; ++e) H.entries[(size_t)e * H.n_units + unit] = stack_read<SPILL>(st, (int)e);
+            meta = n | kMetaTouched;
+            H.first[unit] = unit_first;
+            if (AA) H.first_sample[unit] = unit_first_sample;
+            atomicOr(&H.touched[unit >> 5], 1u << (unit & 31u));
+          }
+          H.meta[unit] = meta;
+        }
+        if (LIT == 2) {  // a changed leftover goes to the unit's other slot and sends the successor to the next round
+          const uint32_t meta = H.meta[unit];
+          const uint32_t cur = (meta >> 16) & 1u, cnt = meta & 0xffffu;
+          uint32_t n = (uint32_t)st.sp;
+          if (n > H.cap) { atomicOr(P.status, kHoErrLeftoverCap); n = H.cap; }
+          bool same = n == cnt;
+          for (uint32_t e = 0; same && e < n; ++e) {
+            const uint2 a = H.entries[((size_t)cur * H.cap + e) * H.n_units + unit], b = stack_read<SPILL>(st, (int)e);
+            same = a.x == b.x && a.y == b.y;
+          }
+          H.first[unit] = unit_first;
+          if (!same) {
+            const uint32_t nb = cur ^ 1u;
+            for (uint32_t e = 0; e < n; ++e) H.entries[((size_t)nb * H.cap + e) * H.n_units + unit] = stack_read<SPILL>(st, (int)e);
+            H.meta[unit] = n | (nb << 16) | kMetaTouched;
+            const int succ = handoff_succ(H, unit);
+            if (succ >= 0) handoff_append(list_out, n_out_p, H.list_cap, H.counters, make_uint4((uint32_t)succ, unit, (nb << 16) | n, 1u));
+          }
+        }
       }
+      if (LIT != 2) break;
     }
+    if (LIT != 2 || !H.persistent) break;
+    // next round of the persistent workgroup: what was written becomes the work list; the one just done is emptied
+    __threadfence();
+    if (lane == 0) __hip_atomic_store(n_in_p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    uint4* tl = list_in; list_in = list_out; list_out = tl;
+    uint32_t* tn = n_in_p; n_in_p = n_out_p; n_out_p = tn;
   }
   if (STATS) flush_stats<STATS>(ct, P.stats);
-  record_tile_cost(P, tx, ty, t_begin);
+  if (LIT != 2 && !halo_block) record_tile_cost(P, tx, ty, t_begin);
   P3D_TL_END()
+}
+
+// Round 1 of the hand-off for a whole launch: every unit that touched the stack and whose predecessor left something
+// re-traces its first closest hit on that leftover; the units whose hit changed go on the work list of the redo launch.
+template <bool LDS, bool SPILL>
+__global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParams P) {
+  extern __shared__ float4 smem[];
+  uint32_t tx = 0, ty = 0;
+  const bool halo_block = blockIdx.x >= P.tile_blocks;
+  if (!halo_block && !tile_of_block(P, tx, ty)) return;
+  DevScene sc = P.sc;
+  stage_scene<LDS>(sc, P, smem);
+  const uint32_t lane = threadIdx.x;
+  const Handoff& H = P.hand;
+  Counters<false> ct;
+  Stack st;
+  st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
+  st.spill = P.spill + (blockIdx.x * kBlock + lane);
+  st.spill_stride = P.level_stride;
+  st.sp = 0;
+  st.cap = P.stack_cap;
+  uint32_t unit = 0;
+  bool active;
+  if (halo_block) {
+    active = halo_unit_of_lane(P, lane, unit);
+  } else {
+    const int c = (int)(tx * 8 + (lane % 8)), r = (int)(ty * 8 + (lane / 8));
+    active = c < P.w && r < P.h;
+    unit = (uint32_t)(P.row0 + r) * H.row_units + H.halo + (uint32_t)c;
+  }
+  if (!active || !handoff_touched(H, unit)) return;
+  const int pred = handoff_pred(H, unit);
+  if (pred < 0) return;
+  const uint32_t pm = H.meta[pred];
+  if ((pm & 0xffffu) == 0) return;  // the predecessor left nothing: pass 1's empty stack was right
+  const UnitPlace up = place_of_unit(P, unit);
+  const uint32_t slot_count = pm & 0x1ffffu;
+  seed_stack<SPILL>(st, H, (uint32_t)pred, slot_count, ct);
+  atomicAdd(&H.counters[kHoChecked], 1u);
+  const float4 now = first_closest_hit<SPILL>(P, sc, st, up.x, up.y, P.antialiasing ? H.first_sample[unit] : 0u, ct);
+  if (!same_first(now, H.first[unit]))
+    handoff_append(H.list_out, H.n_out, H.list_cap, H.counters, make_uint4(unit, (uint32_t)pred, slot_count, 0u));
 }
 
 // ---------------------------------------------------------------------------

@@ -74,11 +74,13 @@ struct SchedEntry {
   hipEvent_t ready = nullptr;
   hipStream_t built_on = nullptr;
   uint64_t last_use = 0;
+  bool built = false;  // the recording launch and sched_build_kernel were enqueued: `sched` may be used
   bool same_key(const SchedEntry& o) const {
     return accel == o.accel && aa == o.aa && spp == o.spp && pt == o.pt && max_depth == o.max_depth && x0 == o.x0 && y0 == o.y0 &&
            w == o.w && h == o.h && stripe_h == o.stripe_h && stripe_stride == o.stripe_stride;
   }
 };
+uint32_t g_debug_trip_bound = 0;  // tests: force the sample hand-out loops of the SUB = 4 kernels to give up early
 constexpr size_t kSchedCacheEntries = 16;
 constexpr uint32_t kSchedMinTiles = 8192;  // with fewer tiles than ~2 per wave slot nearly all start at once anyway
 
@@ -100,8 +102,12 @@ struct p3d_scene {
   bool has_bvh = false, has_grid = false;
   uint32_t bvh_max_depth = 0;
   float device_bvh_ms = 0;  // GPU time of lbvh::build, 0 for an uploaded tree
-  Scratch levels, spill, out_rgb, out_hit, out_rgb8, q_in, q_out;
+  Scratch levels, spill, deferred, out_rgb, out_hit, out_rgb8, q_in, q_out;
+  // P3D_STACK_LITERAL (csrc/handoff.hpp): leftovers, per-unit records, work lists, counters
+  Scratch ho_entries, ho_meta, ho_first, ho_first_sample, ho_touched, ho_lists, ho_counters, ho_row_chain, ho_halo_pix;
+  bool zero_weight_reflections = false;  // some material is transmissive AND reflective (main.cpp:282,290-300)
   unsigned long long* d_stats = nullptr;
+  uint32_t* d_status = nullptr;          // kHoErr* bits raised by kernels; read and cleared by check_status()
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -128,7 +134,10 @@ void p3d_scene_destroy(p3d_scene* s) {
     e.sched.release();
     if (e.ready) (void)hipEventDestroy(e.ready);
   }
-  s->levels.release(); s->spill.release(); s->out_rgb.release(); s->out_hit.release();
+  s->levels.release(); s->spill.release(); s->deferred.release(); s->out_rgb.release(); s->out_hit.release();
+  s->ho_entries.release(); s->ho_meta.release(); s->ho_first.release(); s->ho_first_sample.release(); s->ho_touched.release();
+  s->ho_lists.release(); s->ho_counters.release(); s->ho_row_chain.release(); s->ho_halo_pix.release();
+  if (s->d_status) (void)hipFree(s->d_status);
   s->out_rgb8.release(); s->q_in.release(); s->q_out.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -199,7 +208,8 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
     dst[2] = make_float4(p.v[8], tmf, objf, 0.f);
   };
   std::vector<float4> blob;
-  auto s = std::unique_ptr<p3d_scene>(new p3d_scene());
+  // every early return below frees what was allocated so far (device memory, events)
+  auto s = std::unique_ptr<p3d_scene, void (*)(p3d_scene*)>(new p3d_scene(), &p3d_scene_destroy);
   s->device = device;
   s->off_nodes = (uint32_t)blob.size();
   for (uint32_t i = 0; i < d->n_bvh_nodes; ++i) {
@@ -323,6 +333,10 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
     s->has_grid = true;
   }
   P3D_HIP(hipMalloc((void**)&s->d_stats, kNumStats * sizeof(unsigned long long)));
+  P3D_HIP(hipMalloc((void**)&s->d_status, sizeof(uint32_t)));
+  P3D_HIP(hipMemset(s->d_status, 0, sizeof(uint32_t)));
+  for (uint32_t i = 0; i < d->n_materials; ++i)
+    if (d->materials[i].transmittance != 0 && d->materials[i].reflection > 0) s->zero_weight_reflections = true;
   P3D_HIP(hipEventCreate(&s->ev0));
   P3D_HIP(hipEventCreate(&s->ev1));
   *out = s.release();
@@ -392,6 +406,30 @@ hipError_t launch_accel(bool pt, bool aa, bool sub4, bool lds_scene, bool stats,
   return stats ? launch_one<ACCEL, false, true>(pt, aa, sub4, P, blocks, lds, st) : launch_one<ACCEL, false, false>(pt, aa, sub4, P, blocks, lds, st);
 }
 
+// P3D_STACK_LITERAL launches (BVH only).  lit 1: pass 1; lit 2: work-list launch (no counters).
+template <bool LDS, bool SPILL>
+hipError_t launch_literal_variant(int lit, bool aa, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+  constexpr int A = P3D_ACCEL_BVH;
+  if (lit == 1) {
+    if (aa && stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, true, SPILL, 1, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
+    else if (aa) hipLaunchKernelGGL((whitted_kernel<A, LDS, false, true, SPILL, 1, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
+    else if (stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, false, SPILL, 1, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
+    else hipLaunchKernelGGL((whitted_kernel<A, LDS, false, false, SPILL, 1, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
+  } else if (lit == 2) {
+    if (aa) hipLaunchKernelGGL((whitted_kernel<A, LDS, false, true, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
+    else hipLaunchKernelGGL((whitted_kernel<A, LDS, false, false, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
+  } else {
+    hipLaunchKernelGGL((handoff_check_kernel<LDS, SPILL>), dim3(blocks), dim3(kBlock), lds, st, P);
+  }
+  return hipGetLastError();
+}
+// lit 0 here = the check kernel
+hipError_t launch_literal(int lit, bool aa, bool lds_scene, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+  if (lds_scene && P.stack_spills) return launch_literal_variant<true, true>(lit, aa, stats, P, blocks, lds, st);
+  if (lds_scene) return launch_literal_variant<true, false>(lit, aa, stats, P, blocks, lds, st);
+  return launch_literal_variant<false, true>(lit, aa, stats, P, blocks, lds, st);
+}
+
 // Looks up the schedule for the launch described by (cfg, P).  Known key: P.sched is set.  New
 // key: P.tile_cost is set so that this launch (in frame order) records the costs, and *fresh
 // points at the entry, to be completed by schedule_finish() right after the launch.
@@ -402,7 +440,7 @@ int schedule_lookup(p3d_scene* s, const p3d_config* cfg, bool pt, RenderParams& 
   key.max_depth = P.max_depth; key.x0 = P.x0; key.y0 = P.y0; key.w = P.w; key.h = P.h;
   key.stripe_h = P.stripe_h; key.stripe_stride = P.stripe_stride;
   for (SchedEntry& c : s->sched)
-    if (c.same_key(key)) {
+    if (c.built && c.same_key(key)) {
       if (c.built_on != st) P3D_HIP(hipStreamWaitEvent(st, c.ready, 0));
       c.last_use = ++s->sched_clock;
       P.sched = (const uint32_t*)c.sched.p;
@@ -415,9 +453,10 @@ int schedule_lookup(p3d_scene* s, const p3d_config* cfg, bool pt, RenderParams& 
   } else {  // recycle the least recently used entry once the work queued with it has drained
     e = &s->sched[0];
     for (SchedEntry& c : s->sched)
-      if (c.last_use < e->last_use) e = &c;
+      if (!c.built || c.last_use < e->last_use) e = &c;
     P3D_HIP(hipDeviceSynchronize());
   }
+  e->built = false;
   const uint32_t n = P.tiles_x * P.tiles_y;
   if (int rc = e->cost.ensure((size_t)n * sizeof(uint32_t))) return rc;
   if (int rc = e->sched.ensure((size_t)n * sizeof(uint32_t))) return rc;
@@ -434,6 +473,7 @@ int schedule_finish(p3d_scene* s, SchedEntry* e, uint32_t n_tiles, hipStream_t s
   if (hipError_t err = hipGetLastError(); err != hipSuccess)
     return fail(P3D_ERR_NO_DEVICE, std::string("schedule kernel launch: ") + hipGetErrorString(err));
   P3D_HIP(hipEventRecord(e->ready, st));
+  e->built = true;
   e->built_on = st;
   e->last_use = ++s->sched_clock;
   return P3D_OK;
@@ -455,7 +495,21 @@ uint32_t stack_bound(const p3d_scene* s, uint32_t accel, bool whitted) {
 }
 
 
-int finish_stats(p3d_scene* s, hipStream_t st, p3d_stats* stats) {
+// Device-detected errors (sample hand-out loop hit its trip bound, a leftover outgrew its slot, the hand-off found no
+// fixed point): read and clear the status word.  Call only where the stream has been synchronised.
+int check_status(p3d_scene* s) {
+  uint32_t h = 0;
+  P3D_HIP(hipMemcpy(&h, s->d_status, sizeof(h), hipMemcpyDeviceToHost));
+  if (!h) return P3D_OK;
+  P3D_HIP(hipMemset(s->d_status, 0, sizeof(uint32_t)));
+  std::string what;
+  if (h & kHoErrTrips) what += " sample hand-out loop reached its trip bound (pixels would miss samples);";
+  if (h & kHoErrLeftoverCap) what += " a hit_stack leftover outgrew its slot;";
+  if (h & kHoErrNoFixedPoint) what += " hit_stack hand-off did not reach a fixed point;";
+  return fail(P3D_ERR_CAPACITY, "device-detected error:" + what);
+}
+
+int finish_stats(p3d_scene* s, hipStream_t st, p3d_stats* stats, bool literal) {
   P3D_HIP(hipEventRecord(s->ev1, st));
   P3D_HIP(hipEventSynchronize(s->ev1));
   float ms = 0;
@@ -469,7 +523,13 @@ int finish_stats(p3d_scene* s, hipStream_t st, p3d_stats* stats) {
   stats->node_tests = h[kNodeTests]; stats->sphere_tests = h[kSphereTests]; stats->tri_tests = h[kTriTests];
   stats->box_tests = h[kBoxTests]; stats->plane_tests = h[kPlaneTests]; stats->shaded_hits = h[kShadedHits];
   stats->pixels = h[kPixels]; stats->max_stack = h[kMaxStack];
-  return P3D_OK;
+  if (literal) {
+    uint32_t c[kHoNumCounters];
+    P3D_HIP(hipMemcpy(c, s->ho_counters.p, sizeof(c), hipMemcpyDeviceToHost));
+    stats->handoff_checked = c[kHoChecked]; stats->handoff_redone = c[kHoRedone]; stats->handoff_rounds = c[kHoRounds];
+    if (c[kHoError]) return fail(P3D_ERR_CAPACITY, "hit_stack hand-off: work list overflow");
+  }
+  return check_status(s);
 }
 
 }  // namespace
@@ -492,6 +552,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   }
   if (cfg->integrator > P3D_PATHTRACE || cfg->sample_mode > P3D_SAMPLE_TENT) return fail(P3D_ERR_INVALID, "bad integrator / sample_mode");
   if (cfg->tile_order > P3D_TILE_ORDER_FRAME) return fail(P3D_ERR_INVALID, "bad tile_order");
+  if (cfg->stack_mode > P3D_STACK_PER_PIXEL) return fail(P3D_ERR_INVALID, "bad stack_mode");
   if (cfg->max_depth < 0 || cfg->max_depth > 1024) return fail(P3D_ERR_INVALID, "max_depth out of range");
   if (cfg->antialiasing && (cfg->spp_sqrt == 0 || cfg->spp_sqrt > 1024)) return fail(P3D_ERR_INVALID, "spp_sqrt out of range");
   if (cfg->soft_shadows && !cfg->antialiasing)
@@ -503,6 +564,9 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
 
   // main.cpp:804-812: without ANTIALIASING the frame loop always calls rayTracing
   const bool pt = cfg->integrator == P3D_PATHTRACE && cfg->antialiasing;
+  // Only rayTracing over the BVH has a stack that survives a query (bvh.cpp:86,322); Radiance asks closest-hit
+  // queries only, which leave it empty (bvh.cpp:256-274), the grid and the object loop have none.
+  const bool literal = cfg->stack_mode == P3D_STACK_LITERAL && !pt && cfg->accel == P3D_ACCEL_BVH;
   // worst-case node-stack height (stack_bound).  LDS-staged scenes keep the WHOLE stack in LDS
   // (kernel variant without a spill path); deep trees / many lights use the global-memory variant,
   // which holds the first `cap` entries in LDS and spills the rest.
@@ -533,22 +597,27 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   P.skybox = cfg->skybox ? 1u : 0u;
   P.stripe_h = tile->stripe_h > 0 ? tile->stripe_h : 0; P.stripe_stride = ss;
   P.stats = s->d_stats;
+  P.status = s->d_status;
+  P.debug_trip_bound = g_debug_trip_bound;
   P.stack_cap = (int32_t)cap;
   P.stack_spills = lds_spill ? 1u : 0u;
   P.lds_scene_f4 = lds_scene ? s->blob_f4 : 0;
   // path tracer with >= 16 samples per pixel: four lanes per pixel, 4x4-pixel tiles (pt_kernel SUB = 4)
-  // ... and anti-aliased Whitted launches with >= 4 samples per pixel over a scene traversed from L2 (whitted_kernel SUB = 4)
+  // ... and anti-aliased Whitted launches with >= 4 samples per pixel over a scene traversed from L2 (whitted_kernel SUB = 4),
+  // unless the samples of a pixel have to hand the stack to each other in order (LITERAL)
   const bool sub4 = (pt && cfg->spp_sqrt >= kPtSub4MinSppSqrt) ||
-                    (!pt && !lds_scene && cfg->antialiasing && cfg->spp_sqrt >= kWhittedSub4MinSppSqrt);
+                    (!pt && !literal && !lds_scene && cfg->antialiasing && cfg->spp_sqrt >= kWhittedSub4MinSppSqrt);
   const uint32_t tp = sub4 ? 4 : 8;  // tile edge in pixels
   const size_t lds_bytes = (size_t)P.lds_scene_f4 * sizeof(float4) + (size_t)cap * kBlock * sizeof(uint2) +
                            (sub4 ? sizeof(PtPixelShared) : 0);
 
   // rows per launch: whole 8-row tile bands, at most kMaxLaunchThreads threads
   const uint32_t tiles_x = ((uint32_t)tile->w + tp - 1) / tp;
-  // per-thread global scratch: Whitted level records, or the path tracer's two deferred dielectric branches
+  // per-thread global scratch: Whitted level records (+ the zero-weight reflection rays a LITERAL launch puts aside),
+  // or the path tracer's two deferred dielectric branches
   const uint32_t levels = pt ? 2 * 3 : (uint32_t)cfg->max_depth;
-  const size_t scratch_per_thread = (size_t)levels * sizeof(float4) + (size_t)spill_entries * sizeof(uint2);
+  const uint32_t deferred = (literal && s->zero_weight_reflections) ? 2u * (uint32_t)std::max(cfg->max_depth, 1) : 0u;
+  const size_t scratch_per_thread = (size_t)(levels + deferred) * sizeof(float4) + (size_t)spill_entries * sizeof(uint2);
   const uint32_t launch_threads = (uint32_t)std::min<size_t>(kMaxLaunchThreads, kLaunchScratchBudget / std::max<size_t>(scratch_per_thread, 1));
   uint32_t bands_per_launch = std::max<uint32_t>(1, launch_threads / (tiles_x * kBlock));
   const uint32_t total_bands = ((uint32_t)tile->h + tp - 1) / tp;
@@ -566,51 +635,140 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   const uint32_t max_threads = blocks_for(tiles_x * bands_per_launch) * kBlock;
   if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * max_threads * sizeof(float4)))) return rc;
   if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)spill_entries * max_threads * sizeof(uint2)))) return rc;
+  if (int rc = s->deferred.ensure(std::max<size_t>(16, (size_t)deferred * max_threads * sizeof(float4)))) return rc;
   P.levels = (float4*)s->levels.p;
   P.spill = (uint2*)s->spill.p;
+  P.deferred = (float4*)s->deferred.p;
+
+  // ---- P3D_STACK_LITERAL: per-unit records of the hit_stack hand-off (csrc/handoff.hpp) ----
+  Handoff& H = P.hand;
+  uint4* ho_list[3] = {nullptr, nullptr, nullptr};
+  uint32_t* ho_counters = nullptr;
+  if (literal) {
+    const uint32_t per = s->bvh_max_depth > 1 ? s->bvh_max_depth - 1 : 1;
+    H.halo = 0;
+    H.row_units = (uint32_t)tile->w + H.halo;
+    H.rows = (uint32_t)tile->h;
+    if ((uint64_t)H.rows * H.row_units >= 0xffffffffull) return fail(P3D_ERR_CAPACITY, "tile too large for the hit_stack hand-off");
+    H.n_units = H.rows * H.row_units;
+    // what a pixel can leave behind: the entries its last shading point's feelers left (Q2), one tree path per light
+    H.cap = std::max<uint32_t>(1, std::min<uint32_t>(bound, s->dev.n_lights * per));
+    if (H.cap > 0xffffu) return fail(P3D_ERR_CAPACITY, "hit_stack leftover bound exceeds 65535 entries (lights x tree depth)");
+    const size_t entry_bytes = (size_t)2 * H.cap * H.n_units * sizeof(uint2);
+    if (entry_bytes > ((size_t)64 << 30)) return fail(P3D_ERR_CAPACITY, "hit_stack hand-off records exceed 64 GiB: render the frame in smaller tiles or use P3D_STACK_PER_PIXEL");
+    if (int rc = s->ho_entries.ensure(entry_bytes)) return rc;
+    if (int rc = s->ho_meta.ensure((size_t)H.n_units * 4)) return rc;
+    if (int rc = s->ho_first.ensure((size_t)H.n_units * sizeof(float4))) return rc;
+    if (int rc = s->ho_first_sample.ensure(cfg->antialiasing ? (size_t)H.n_units * 4 : 16)) return rc;
+    const size_t touched_bytes = ((size_t)H.n_units / 32 + 2) * 4;
+    if (int rc = s->ho_touched.ensure(touched_bytes)) return rc;
+    if (int rc = s->ho_lists.ensure((size_t)3 * H.n_units * sizeof(uint4))) return rc;
+    if (int rc = s->ho_counters.ensure(kHoNumCounters * sizeof(uint32_t))) return rc;
+    H.entries = (uint2*)s->ho_entries.p;
+    H.meta = (uint32_t*)s->ho_meta.p;
+    H.first = (float4*)s->ho_first.p;
+    H.first_sample = (uint32_t*)s->ho_first_sample.p;
+    H.touched = (uint32_t*)s->ho_touched.p;
+    H.row_chain = nullptr;
+    H.halo_pix = nullptr;
+    H.list_cap = H.n_units;
+    H.max_rounds = H.n_units + 2;
+    for (int i = 0; i < 3; ++i) ho_list[i] = (uint4*)s->ho_lists.p + (size_t)i * H.n_units;
+    ho_counters = (uint32_t*)s->ho_counters.p;
+    H.counters = ho_counters;
+    P3D_HIP(hipMemsetAsync(s->ho_touched.p, 0, touched_bytes, st));
+    P3D_HIP(hipMemsetAsync(s->ho_counters.p, 0, kHoNumCounters * sizeof(uint32_t), st));
+  }
 
   if (stats) {
     P3D_HIP(hipMemsetAsync(s->d_stats, 0, kNumStats * sizeof(unsigned long long), st));
     P3D_HIP(hipEventRecord(s->ev0, st));
   }
-  for (uint32_t band0 = 0; band0 < total_bands; band0 += bands_per_launch) {
-    const uint32_t nb = std::min(bands_per_launch, total_bands - band0);
-    const int row0 = (int)(band0 * tp);
-    const int rows = std::min<int>((int)(nb * tp), tile->h - row0);
-    // a chunk starts at local row row0; stripes make the image row a function of the LOCAL
-    // row of the whole tile, so pass the tile origin and offset the outputs instead
-    P.x0 = tile->x0; P.w = tile->w;
-    P.h = rows;
-    if (P.stripe_h > 0) {
-      if (row0 % sh != 0 && nb != total_bands) return fail(P3D_ERR_UNSUPPORTED, "stripe_h must divide the tile bands when a frame is split into several launches");
-      P.y0 = tile->y0 + (row0 / sh) * sh * ss + (row0 % sh);
-    } else {
-      P.y0 = tile->y0 + row0;
+  // pass: 0 = the render launches (LITERAL: pass 1, everything on an empty stack); 1 = LITERAL only: the check launches
+  for (int pass = 0; pass < (literal ? 2 : 1); ++pass) {
+    for (uint32_t band0 = 0; band0 < total_bands; band0 += bands_per_launch) {
+      const uint32_t nb = std::min(bands_per_launch, total_bands - band0);
+      const int row0 = (int)(band0 * tp);
+      const int rows = std::min<int>((int)(nb * tp), tile->h - row0);
+      // a chunk starts at local row row0; stripes make the image row a function of the LOCAL
+      // row of the whole tile, so pass the tile origin and offset the outputs instead
+      P.x0 = tile->x0; P.w = tile->w;
+      P.h = rows;
+      P.row0 = row0;
+      if (P.stripe_h > 0) {
+        if (row0 % sh != 0 && nb != total_bands) return fail(P3D_ERR_UNSUPPORTED, "stripe_h must divide the tile bands when a frame is split into several launches");
+        P.y0 = tile->y0 + (row0 / sh) * sh * ss + (row0 % sh);
+      } else {
+        P.y0 = tile->y0 + row0;
+      }
+      P.tiles_x = tiles_x; P.tiles_y = nb;
+      P.xcd_chunk = xcd_chunk;
+      P.sched = nullptr;
+      P.tile_cost = nullptr;
+      SchedEntry* fresh = nullptr;
+      if (pass == 0 && sched_ok && tiles_x * nb >= kSchedMinTiles)
+        if (int rc = schedule_lookup(s, cfg, pt, P, st, &fresh)) return rc;
+      const uint32_t blocks = blocks_for(tiles_x * nb);
+      P.tile_blocks = blocks;
+      P.level_stride = blocks * kBlock;
+      const size_t off = (size_t)row0 * tile->w;
+      P.rgb = d_rgb ? d_rgb + 3 * off : nullptr;
+      P.hit_id = d_hit ? d_hit + off : nullptr;
+      P.rgb8 = d_rgb8 ? d_rgb8 + 3 * off : nullptr;
+      hipError_t e;
+      if (literal) {
+        if (pass == 1) { H.list_out = ho_list[0]; H.n_out = ho_counters + kHoListA; }
+        e = launch_literal(pass == 0 ? 1 : 0, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
+      } else {
+        switch (cfg->accel) {
+          case P3D_ACCEL_BVH: e = launch_accel<P3D_ACCEL_BVH>(pt, cfg->antialiasing != 0, sub4, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+          case P3D_ACCEL_GRID: e = launch_accel<P3D_ACCEL_GRID>(pt, cfg->antialiasing != 0, sub4, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+          default: e = launch_accel<P3D_ACCEL_NONE>(pt, cfg->antialiasing != 0, sub4, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
+        }
+      }
+      if (e != hipSuccess) {
+        if (fresh) fresh->built = false;
+        return fail(P3D_ERR_NO_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
+      }
+      if (fresh)
+        if (int rc = schedule_finish(s, fresh, tiles_x * nb, st)) return rc;
     }
-    P.tiles_x = tiles_x; P.tiles_y = nb;
-    P.xcd_chunk = xcd_chunk;
-    P.sched = nullptr;
-    P.tile_cost = nullptr;
-    SchedEntry* fresh = nullptr;
-    if (sched_ok && tiles_x * nb >= kSchedMinTiles)
-      if (int rc = schedule_lookup(s, cfg, pt, P, st, &fresh)) return rc;
-    const uint32_t blocks = blocks_for(tiles_x * nb);
-    P.level_stride = blocks * kBlock;
-    const size_t off = (size_t)row0 * tile->w;
-    P.rgb = d_rgb ? d_rgb + 3 * off : nullptr;
-    P.hit_id = d_hit ? d_hit + off : nullptr;
-    P.rgb8 = d_rgb8 ? d_rgb8 + 3 * off : nullptr;
-    hipError_t e;
-    switch (cfg->accel) {
-      case P3D_ACCEL_BVH: e = launch_accel<P3D_ACCEL_BVH>(pt, cfg->antialiasing != 0, sub4, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
-      case P3D_ACCEL_GRID: e = launch_accel<P3D_ACCEL_GRID>(pt, cfg->antialiasing != 0, sub4, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
-      default: e = launch_accel<P3D_ACCEL_NONE>(pt, cfg->antialiasing != 0, sub4, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
-    }
-    if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
-    if (fresh)
-      if (int rc = schedule_finish(s, fresh, tiles_x * nb, st)) return rc;
   }
-  if (stats) return finish_stats(s, st, stats);
+  if (literal) {
+    // Work-list launches over the whole tile: A (units whose first closest hit changed under the predecessor's pass-1
+    // leftover) is rendered again and writes B (successors of units whose own leftover changed); B is checked, and
+    // rendered again where needed, into C; whatever is left after that — almost never anything — is iterated to the
+    // fixed point by one persistent workgroup (C -> A -> C ...).
+    P.x0 = tile->x0; P.w = tile->w; P.h = tile->h; P.row0 = 0; P.y0 = tile->y0;
+    P.rgb = d_rgb; P.hit_id = d_hit; P.rgb8 = d_rgb8;
+    P.sched = nullptr; P.tile_cost = nullptr;
+    // workgroups of a work-list launch: far fewer units than pixels are expected (grid-stride loop for the rest)
+    const uint32_t wide = std::max<uint32_t>(1, std::min<uint32_t>(max_threads / kBlock, std::min<uint32_t>(2048, std::max<uint32_t>(64, H.n_units / 1024))));
+    for (int round = 0; round < 3; ++round) {
+      H.list_in = ho_list[round]; H.n_in = ho_counters + kHoListA + round;
+      H.list_out = ho_list[(round + 1) % 3]; H.n_out = ho_counters + kHoListA + (round + 1) % 3;
+      H.persistent = round == 2 ? 1u : 0u;
+      const uint32_t blocks = round == 2 ? 1u : wide;
+      P.level_stride = blocks * kBlock;
+      P.tile_blocks = blocks;
+      if (round == 2) P3D_HIP(hipMemsetAsync(ho_counters + kHoListA, 0, sizeof(uint32_t), st));  // A was consumed by round 0
+      const hipError_t e = launch_literal(2, cfg->antialiasing != 0, lds_scene, false, P, blocks, lds_bytes, st);
+      if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("hand-off kernel launch: ") + hipGetErrorString(e));
+    }
+  }
+  if (stats) return finish_stats(s, st, stats, literal);
+  return P3D_OK;
+}
+
+int p3d_scene_status(p3d_scene* s) {
+  if (!s) return fail(P3D_ERR_INVALID, "p3d_scene_status: null argument");
+  P3D_HIP(hipSetDevice(s->device));
+  P3D_HIP(hipDeviceSynchronize());
+  return check_status(s);
+}
+
+int p3d_debug_set_trip_bound(uint32_t trips) {
+  g_debug_trip_bound = trips;
   return P3D_OK;
 }
 
@@ -630,7 +788,7 @@ int p3d_render_tile(p3d_scene* s, const p3d_config* cfg, const p3d_tile* tile, f
   if (rgb) P3D_HIP(hipMemcpy(rgb, s->out_rgb.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
   if (hit_id) P3D_HIP(hipMemcpy(hit_id, s->out_hit.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (rgb8) P3D_HIP(hipMemcpy(rgb8, s->out_rgb8.p, n * 3, hipMemcpyDeviceToHost));
-  return P3D_OK;
+  return P3D_OK;  // device-detected errors were turned into a return code by finish_stats()
 }
 
 static int trace_common(p3d_scene* s, uint32_t accel, uint32_t n, const float* origin, const float* direction, int32_t* hit_id,

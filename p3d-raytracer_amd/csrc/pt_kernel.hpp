@@ -132,13 +132,17 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
     // only way round, LLVM split the wait cycle off as an inner loop for the brute-force and grid
     // instantiations and the waiting lanes starved the working ones.)  The trip bound is a backstop:
     // no lane can need more trips than the pixel's whole sample set traced by one lane.
-    const unsigned long long trips_max = (unsigned long long)n_samples * (unsigned)(MAXD + 2) * 4ull + 1024ull;
+    const unsigned long long trips_max = P.debug_trip_bound ? (unsigned long long)P.debug_trip_bound
+                                                            : (unsigned long long)n_samples * (unsigned)(MAXD + 2) * 4ull + 1024ull;
     uint32_t trips_left = trips_max > 0xffffffffull ? 0xffffffffu : (uint32_t)trips_max;
     bool done = false, holding = false;
     const uint32_t spp_magic = (uint32_t)((0x100000000ull + (unsigned)SPP - 1) / (unsigned)SPP);
     while (true) {
       if (SUB == 4) {
-        if (trips_left-- == 0) done = true;
+        if (trips_left-- == 0) {  // the pixel would be written with samples missing: the call fails (P3D_ERR_CAPACITY)
+          if (!done) atomicOr(P.status, kHoErrTrips);
+          done = true;
+        }
         if (__ballot(!done) == 0) break;
         if (done) continue;
       }

@@ -36,5 +36,6 @@ void p3d_config_default(p3d_config* c) {
   c->skybox = 0;                   // SKYBOX is true as shipped, but the cubemap must be supplied first
   c->tile_order = P3D_TILE_ORDER_COST;  // scheduling only
   c->seed = 0x5EED;
+  c->stack_mode = P3D_STACK_LITERAL;    // one hit_stack for the whole frame, as the reference's BVH member (bvh.cpp:86)
 }
 }
