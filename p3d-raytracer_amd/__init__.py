@@ -115,7 +115,7 @@ class Stats(C.Structure):
         "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "rays_bounce", "rays_light",
         "node_tests", "sphere_tests", "tri_tests", "box_tests", "plane_tests", "shaded_hits", "pixels",
         "max_stack")] + [("kernel_ms", C.c_double)] + [(n, C.c_uint64) for n in (
-        "handoff_checked", "handoff_redone", "handoff_rounds")]
+        "handoff_checked", "handoff_redone", "handoff_rounds")] + [("pass1_ms", C.c_double), ("handoff_ms", C.c_double)]
 
     @property
     def rays(self):

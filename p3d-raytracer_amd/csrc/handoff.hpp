@@ -32,7 +32,7 @@ constexpr uint32_t kHaloChain = 8;        // frame pixels rendered in front of a
 constexpr uint32_t kMetaTouched = 1u << 17;
 constexpr uint32_t kNoUnit = 0xffffffffu;
 
-enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoError, kHoListA, kHoListB, kHoListC, kHoNumCounters };
+enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoError, kHoListA, kHoListB, kHoListC, kHoListD, kHoNumCounters };
 constexpr uint32_t kHoErrLeftoverCap = 1u;   // a leftover had more entries than a slot holds
 constexpr uint32_t kHoErrNoFixedPoint = 2u;  // round bound reached
 constexpr uint32_t kHoErrTrips = 4u;         // sample hand-out loop hit its trip bound (SUB = 4 kernels)
@@ -46,6 +46,8 @@ struct Handoff {
   uint32_t persistent;  // list kernel: one workgroup, loop over rounds until the list stays empty
   uint32_t list_cap;
   uint32_t max_rounds;
+  uint32_t count;       // keep the checked / redone statistics (one contended atomic per wave: only on request)
+  uint32_t lanes;       // list kernel: list entries per wave (fewer = less divergence between unrelated pixels)
   uint2* entries;          // [2][cap][n_units]  leftover stacks, two slots per unit
   uint32_t* meta;          // [n_units] bits 0..15 entries of the current slot, bit 16 which slot, bit 17 touched
   float4* first;           // [n_units] {hit point, object id} of the first closest hit of the first touching sample

@@ -193,6 +193,18 @@ __global__ void __launch_bounds__(kSchedBuildThreads) sched_build_kernel(const u
   for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) sched[atomicAdd(&cursor[sched_class(cost[t], mean)], 1u)] = t;
 }
 
+// One launch instead of a hipMemsetAsync per buffer (each of those is a fill kernel of its own, ~5 us): zeroes up to
+// three word ranges at the head of a frame (counters, touched bits, statistics).
+struct ClearParams {
+  uint32_t* p[3];
+  uint32_t n[3];
+};
+__global__ void __launch_bounds__(256) clear_kernel(const ClearParams C) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  for (int k = 0; k < 3; ++k)
+    for (uint32_t j = i; j < C.n[k]; j += stride) C.p[k][j] = 0;
+}
+
 template <bool STATS>
 __device__ __forceinline__ void flush_stats(Counters<STATS>&, unsigned long long*) {}
 template <>
@@ -365,7 +377,7 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA || LIT == 2) ? P3D_WHITTED_
   if (LIT != 2 && !halo_block && !tile_of_block(P, tx, ty)) return;
   if (LIT == 2) {  // nothing on the list for this workgroup: leave before the scene is staged
     const uint32_t n0 = __hip_atomic_load(P.hand.n_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((size_t)blockIdx.x * kBlock >= (n0 > P.hand.list_cap ? P.hand.list_cap : n0)) return;
+    if ((size_t)blockIdx.x * P.hand.lanes >= (n0 > P.hand.list_cap ? P.hand.list_cap : n0)) return;
   }
   P3D_TL_BEGIN()
   const unsigned long long t_begin = (LIT != 2 && P.tile_cost) ? wall_clock64() : 0;
@@ -410,16 +422,16 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA || LIT == 2) ? P3D_WHITTED_
         if (lane == 0) atomicOr(&H.counters[kHoError], kHoErrNoFixedPoint);
         break;
       }
-      if (blockIdx.x == 0 && lane == 0) atomicAdd(&H.counters[kHoRounds], 1u);
+      if (H.count && blockIdx.x == 0 && lane == 0) atomicAdd(&H.counters[kHoRounds], 1u);
     }
     for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {  // LIT == 2: 64 list entries per trip
       bool active;
       UnitPlace up;
       uint32_t unit = 0, pred = 0, pred_slot_count = 0, flags = 0;
       if (LIT == 2) {
-        if ((size_t)chunk * kBlock >= n_in) break;
-        const uint32_t i = chunk * kBlock + lane;
-        active = i < n_in;
+        if ((size_t)chunk * H.lanes >= n_in) break;
+        const uint32_t i = chunk * H.lanes + lane;
+        active = lane < H.lanes && i < n_in;
         up.c = up.r = up.x = up.y = 0; up.halo = false; up.valid = false;
         if (active) {
           const uint32_t* e = reinterpret_cast<const uint32_t*>(list_in + i);
@@ -451,12 +463,12 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA || LIT == 2) ? P3D_WHITTED_
       if (LIT == 2 && active) {  // seed with the predecessor's leftover; re-trace the first closest hit if asked to
         seed_stack<SPILL>(st, H, pred, pred_slot_count, ct);
         if (flags & 1u) {
-          atomicAdd(&H.counters[kHoChecked], 1u);
+          if (H.count) atomicAdd(&H.counters[kHoChecked], 1u);
           const float4 now = first_closest_hit<SPILL>(P, sc, st, up.x, up.y, AA ? H.first_sample[unit] : 0u, ct);
           if (same_first(now, H.first[unit])) active = false;  // nothing this unit computes can differ
           else seed_stack<SPILL>(st, H, pred, pred_slot_count, ct);
         }
-        if (active) atomicAdd(&H.counters[kHoRedone], 1u);
+        if (active && H.count) atomicAdd(&H.counters[kHoRedone], 1u);
       }
       if (LIT == 1) st.sp = 0;
 
@@ -602,6 +614,51 @@ __global__ void __launch_bounds__(kBlock, (LDS || AA || LIT == 2) ? P3D_WHITTED_
   P3D_TL_END()
 }
 
+// For every tile row that starts a chain of its own (its predecessor in the FRAME is not the end of the tile row above:
+// first row of a stripe, any row of a sub-rectangle, a tile that does not start at the frame's first pixel): the last
+// kHaloChain frame pixels before the row's first pixel that touch the stack, i.e. whose primary ray (any of the pixel's
+// samples) gets past the root test of bvh.cpp:203-205.  They are rendered in front of the row, for their leftovers only;
+// the first of them starts on an empty stack, which is exact if the frame's first touching pixel is among them and
+// otherwise assumes that what a pixel leaves does not depend on a leftover kHaloChain pixels back (every link of that
+// chain would have to change its successor's first hit).  One wave per row walks back 64 pixels at a time.
+__global__ void __launch_bounds__(kBlock) halo_find_kernel(const RenderParams P, uint32_t* halo_pix) {
+  const Handoff& H = P.hand;
+  const uint32_t row = blockIdx.x, lane = threadIdx.x;
+  if (row >= H.rows || !H.row_chain[row]) return;
+  const DevScene& sc = P.sc;
+  const int res_x = sc.cam.res_x;
+  const long long f0 = (long long)image_row(P, (int)row) * res_x + P.x0;  // the row's first pixel: search below it
+  const NodeRec root = load_node(sc.nodes, 0);
+  const int SPP = P.antialiasing ? (int)P.spp_sqrt : 1;
+  uint32_t found = 0;
+  for (long long base = f0; base > 0 && found < kHaloChain; base -= kBlock) {
+    const long long f = base - 1 - (long long)lane;  // lane 0 looks at the most recent pixel
+    bool touched = false;
+    if (f >= 0) {
+      const int x = (int)(f % res_x), y = (int)(f / res_x);
+      for (int s = 0; s < SPP * SPP && !touched; ++s) {
+        Rng rng;
+        rng.state = 0; rng.inc = 1;
+        if (P.antialiasing) rng.seed_stream(P.seed, (uint32_t)(y * res_x + x), (uint32_t)s);
+        F3 o, d;
+        make_primary(P, sc.cam, x, y, s / SPP, s % SPP, rng, o, d);
+        RayS ray;
+        ray_set(ray, o, d);
+        float t;
+        touched = aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, t, false);
+      }
+    }
+    unsigned long long mask = __ballot(touched);
+    while (mask && found < kHaloChain) {  // wave-uniform
+      const int l = __ffsll((long long)mask) - 1;
+      if (lane == 0) halo_pix[row * kHaloChain + (kHaloChain - 1 - found)] = (uint32_t)(base - 1 - l);
+      ++found;
+      mask &= mask - 1;
+    }
+  }
+  if (lane < kHaloChain - found) halo_pix[row * kHaloChain + lane] = kNoUnit;
+}
+
 // Round 1 of the hand-off for a whole launch: every unit that touched the stack and whose predecessor left something
 // re-traces its first closest hit on that leftover; the units whose hit changed go on the work list of the redo launch.
 template <bool LDS, bool SPILL>
@@ -610,17 +667,8 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
   uint32_t tx = 0, ty = 0;
   const bool halo_block = blockIdx.x >= P.tile_blocks;
   if (!halo_block && !tile_of_block(P, tx, ty)) return;
-  DevScene sc = P.sc;
-  stage_scene<LDS>(sc, P, smem);
   const uint32_t lane = threadIdx.x;
   const Handoff& H = P.hand;
-  Counters<false> ct;
-  Stack st;
-  st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
-  st.spill = P.spill + (blockIdx.x * kBlock + lane);
-  st.spill_stride = P.level_stride;
-  st.sp = 0;
-  st.cap = P.stack_cap;
   uint32_t unit = 0;
   bool active;
   if (halo_block) {
@@ -630,15 +678,29 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
     active = c < P.w && r < P.h;
     unit = (uint32_t)(P.row0 + r) * H.row_units + H.halo + (uint32_t)c;
   }
-  if (!active || !handoff_touched(H, unit)) return;
-  const int pred = handoff_pred(H, unit);
-  if (pred < 0) return;
-  const uint32_t pm = H.meta[pred];
-  if ((pm & 0xffffu) == 0) return;  // the predecessor left nothing: pass 1's empty stack was right
+  // which lanes have anything to re-trace is known before the scene is staged: most waves leave here
+  int pred = -1;
+  uint32_t pm = 0;
+  if (active && handoff_touched(H, unit)) {
+    pred = handoff_pred(H, unit);
+    if (pred >= 0) pm = H.meta[pred];
+  }
+  const bool need = (pm & 0xffffu) != 0;  // otherwise the predecessor left nothing: pass 1's empty stack was right
+  if (__ballot(need) == 0) return;
+  DevScene sc = P.sc;
+  stage_scene<LDS>(sc, P, smem);
+  if (!need) return;
+  Counters<false> ct;
+  Stack st;
+  st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
+  st.spill = P.spill + (blockIdx.x * kBlock + lane);
+  st.spill_stride = P.level_stride;
+  st.sp = 0;
+  st.cap = P.stack_cap;
   const UnitPlace up = place_of_unit(P, unit);
   const uint32_t slot_count = pm & 0x1ffffu;
   seed_stack<SPILL>(st, H, (uint32_t)pred, slot_count, ct);
-  atomicAdd(&H.counters[kHoChecked], 1u);
+  if (H.count) atomicAdd(&H.counters[kHoChecked], 1u);
   const float4 now = first_closest_hit<SPILL>(P, sc, st, up.x, up.y, P.antialiasing ? H.first_sample[unit] : 0u, ct);
   if (!same_first(now, H.first[unit]))
     handoff_append(H.list_out, H.n_out, H.list_cap, H.counters, make_uint4(unit, (uint32_t)pred, slot_count, 0u));

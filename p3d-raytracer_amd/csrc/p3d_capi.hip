@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -80,6 +81,18 @@ struct SchedEntry {
            w == o.w && h == o.h && stripe_h == o.stripe_h && stripe_stride == o.stripe_stride;
   }
 };
+#ifndef P3D_REDO_LANES
+#define P3D_REDO_LANES 16
+#endif
+// list entries per wave of the first work-list launch; P3D_REDO_LANES in the environment overrides it (experiments)
+inline uint32_t redo_lanes() {
+  static const uint32_t v = [] {
+    const char* e = getenv("P3D_REDO_LANES");
+    const int n = e ? atoi(e) : P3D_REDO_LANES;
+    return (uint32_t)(n >= 1 && n <= 64 ? n : P3D_REDO_LANES);
+  }();
+  return v;
+}
 uint32_t g_debug_trip_bound = 0;  // tests: force the sample hand-out loops of the SUB = 4 kernels to give up early
 constexpr size_t kSchedCacheEntries = 16;
 constexpr uint32_t kSchedMinTiles = 8192;  // with fewer tiles than ~2 per wave slot nearly all start at once anyway
@@ -105,10 +118,11 @@ struct p3d_scene {
   Scratch levels, spill, deferred, out_rgb, out_hit, out_rgb8, q_in, q_out;
   // P3D_STACK_LITERAL (csrc/handoff.hpp): leftovers, per-unit records, work lists, counters
   Scratch ho_entries, ho_meta, ho_first, ho_first_sample, ho_touched, ho_lists, ho_counters, ho_row_chain, ho_halo_pix;
+  std::vector<int32_t> ho_chain_key;     // tile the row_chain flags on the device were computed for
   bool zero_weight_reflections = false;  // some material is transmissive AND reflective (main.cpp:282,290-300)
   unsigned long long* d_stats = nullptr;
   uint32_t* d_status = nullptr;          // kHoErr* bits raised by kernels; read and cleared by check_status()
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
 };
 
 extern "C" {
@@ -141,6 +155,7 @@ void p3d_scene_destroy(p3d_scene* s) {
   s->out_rgb8.release(); s->q_in.release(); s->q_out.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->ev_mid) (void)hipEventDestroy(s->ev_mid);
   delete s;
 }
 
@@ -339,6 +354,7 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
     if (d->materials[i].transmittance != 0 && d->materials[i].reflection > 0) s->zero_weight_reflections = true;
   P3D_HIP(hipEventCreate(&s->ev0));
   P3D_HIP(hipEventCreate(&s->ev1));
+  P3D_HIP(hipEventCreate(&s->ev_mid));
   *out = s.release();
   return P3D_OK;
 }
@@ -518,6 +534,12 @@ int finish_stats(p3d_scene* s, hipStream_t st, p3d_stats* stats, bool literal) {
   P3D_HIP(hipMemcpy(h, s->d_stats, sizeof(h), hipMemcpyDeviceToHost));
   std::memset(stats, 0, sizeof(*stats));
   stats->kernel_ms = ms;
+  if (literal) {
+    float a = 0;
+    P3D_HIP(hipEventElapsedTime(&a, s->ev0, s->ev_mid));
+    stats->pass1_ms = a;
+    stats->handoff_ms = ms - a;
+  }
   stats->rays_primary = h[kRaysPrimary]; stats->rays_shadow = h[kRaysShadow]; stats->rays_reflect = h[kRaysReflect];
   stats->rays_refract = h[kRaysRefract]; stats->rays_bounce = h[kRaysBounce]; stats->rays_light = h[kRaysLight];
   stats->node_tests = h[kNodeTests]; stats->sphere_tests = h[kSphereTests]; stats->tri_tests = h[kTriTests];
@@ -632,7 +654,9 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // Cost-ordered tiles (DESIGN.md "Tile schedule"): where the frame order leaves a tail of a few
   // long-running tiles — Whitted chains over an LDS-staged scene, more tiles than wave slots.
   const bool sched_ok = lds_scene && cfg->tile_order == P3D_TILE_ORDER_COST && cfg->max_depth > 0;
-  const uint32_t max_threads = blocks_for(tiles_x * bands_per_launch) * kBlock;
+  // LITERAL: workgroups behind the tile grid of the first launch render the halo chains (8 chains of 8 pixels per wave)
+  const uint32_t halo_blocks_max = literal ? ((uint32_t)tile->h * kHaloChain + kBlock - 1) / kBlock : 0;
+  const uint32_t max_threads = (blocks_for(tiles_x * bands_per_launch) + halo_blocks_max) * kBlock;
   if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * max_threads * sizeof(float4)))) return rc;
   if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)spill_entries * max_threads * sizeof(uint2)))) return rc;
   if (int rc = s->deferred.ensure(std::max<size_t>(16, (size_t)deferred * max_threads * sizeof(float4)))) return rc;
@@ -642,11 +666,25 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
 
   // ---- P3D_STACK_LITERAL: per-unit records of the hit_stack hand-off (csrc/handoff.hpp) ----
   Handoff& H = P.hand;
-  uint4* ho_list[3] = {nullptr, nullptr, nullptr};
+  uint4* ho_list[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* ho_counters = nullptr;
+  size_t touched_bytes = 0;
   if (literal) {
     const uint32_t per = s->bvh_max_depth > 1 ? s->bvh_max_depth - 1 : 1;
-    H.halo = 0;
+    // Rows whose predecessor in the frame is not the end of the tile row above start a chain of their own (halo_find_kernel)
+    const bool full_width = tile->x0 == 0 && tile->w == cam.res_x;
+    std::vector<uint8_t> chain((size_t)tile->h, 0);
+    bool any_chain = false;
+    {
+      long long y_prev = -2;
+      for (int r = 0; r < tile->h; ++r) {
+        const long long y = (long long)tile->y0 + (long long)(r / sh) * sh * ss + (r % sh);
+        chain[r] = r == 0 ? !(tile->x0 == 0 && y == 0) : !(full_width && y == y_prev + 1);
+        any_chain = any_chain || chain[r];
+        y_prev = y;
+      }
+    }
+    H.halo = any_chain ? kHaloChain : 0;
     H.row_units = (uint32_t)tile->w + H.halo;
     H.rows = (uint32_t)tile->h;
     if ((uint64_t)H.rows * H.row_units >= 0xffffffffull) return fail(P3D_ERR_CAPACITY, "tile too large for the hit_stack hand-off");
@@ -660,9 +698,9 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     if (int rc = s->ho_meta.ensure((size_t)H.n_units * 4)) return rc;
     if (int rc = s->ho_first.ensure((size_t)H.n_units * sizeof(float4))) return rc;
     if (int rc = s->ho_first_sample.ensure(cfg->antialiasing ? (size_t)H.n_units * 4 : 16)) return rc;
-    const size_t touched_bytes = ((size_t)H.n_units / 32 + 2) * 4;
+    touched_bytes = ((size_t)H.n_units / 32 + 2) * 4;
     if (int rc = s->ho_touched.ensure(touched_bytes)) return rc;
-    if (int rc = s->ho_lists.ensure((size_t)3 * H.n_units * sizeof(uint4))) return rc;
+    if (int rc = s->ho_lists.ensure((size_t)4 * H.n_units * sizeof(uint4))) return rc;
     if (int rc = s->ho_counters.ensure(kHoNumCounters * sizeof(uint32_t))) return rc;
     H.entries = (uint2*)s->ho_entries.p;
     H.meta = (uint32_t*)s->ho_meta.p;
@@ -671,18 +709,42 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     H.touched = (uint32_t*)s->ho_touched.p;
     H.row_chain = nullptr;
     H.halo_pix = nullptr;
+    if (any_chain) {
+      if (int rc = s->ho_row_chain.ensure((size_t)tile->h)) return rc;
+      if (int rc = s->ho_halo_pix.ensure((size_t)tile->h * kHaloChain * 4)) return rc;
+      const std::vector<int32_t> key = {tile->x0, tile->y0, tile->w, tile->h, tile->stripe_h, tile->stripe_stride, cam.res_x, cam.res_y};
+      if (key != s->ho_chain_key) {  // flags unchanged for the same tile: frames of a sequence upload them once
+        P3D_HIP(hipMemcpy(s->ho_row_chain.p, chain.data(), chain.size(), hipMemcpyHostToDevice));
+        s->ho_chain_key = key;
+      }
+      H.row_chain = (const uint8_t*)s->ho_row_chain.p;
+      H.halo_pix = (const uint32_t*)s->ho_halo_pix.p;
+    }
     H.list_cap = H.n_units;
+    H.count = want_counts ? 1u : 0u;
     H.max_rounds = H.n_units + 2;
-    for (int i = 0; i < 3; ++i) ho_list[i] = (uint4*)s->ho_lists.p + (size_t)i * H.n_units;
+    for (int i = 0; i < 4; ++i) ho_list[i] = (uint4*)s->ho_lists.p + (size_t)i * H.n_units;
     ho_counters = (uint32_t*)s->ho_counters.p;
     H.counters = ho_counters;
-    P3D_HIP(hipMemsetAsync(s->ho_touched.p, 0, touched_bytes, st));
-    P3D_HIP(hipMemsetAsync(s->ho_counters.p, 0, kHoNumCounters * sizeof(uint32_t), st));
   }
-
-  if (stats) {
-    P3D_HIP(hipMemsetAsync(s->d_stats, 0, kNumStats * sizeof(unsigned long long), st));
-    P3D_HIP(hipEventRecord(s->ev0, st));
+  if (literal || stats) {  // one clear launch at the head of the frame: statistics, hand-off counters, touched bits
+    ClearParams C{};
+    if (stats) { C.p[0] = (uint32_t*)s->d_stats; C.n[0] = kNumStats * 2; }
+    if (literal) {
+      C.p[1] = ho_counters; C.n[1] = kHoNumCounters;
+      C.p[2] = (uint32_t*)s->ho_touched.p; C.n[2] = (uint32_t)(touched_bytes / 4);
+    }
+    if (stats) P3D_HIP(hipEventRecord(s->ev0, st));
+    const uint32_t words = std::max(C.n[0], std::max(C.n[1], C.n[2]));
+    hipLaunchKernelGGL(clear_kernel, dim3(std::min<uint32_t>(256, (words + 255) / 256)), dim3(256), 0, st, C);
+    P3D_HIP(hipGetLastError());
+  }
+  uint32_t halo_blocks = 0;
+  if (literal && H.halo) {
+    halo_blocks = (H.rows * kHaloChain + kBlock - 1) / kBlock;
+    P.x0 = tile->x0; P.y0 = tile->y0; P.row0 = 0; P.w = tile->w; P.h = tile->h;
+    hipLaunchKernelGGL(halo_find_kernel, dim3(H.rows), dim3(kBlock), 0, st, P, (uint32_t*)s->ho_halo_pix.p);
+    P3D_HIP(hipGetLastError());
   }
   // pass: 0 = the render launches (LITERAL: pass 1, everything on an empty stack); 1 = LITERAL only: the check launches
   for (int pass = 0; pass < (literal ? 2 : 1); ++pass) {
@@ -708,8 +770,9 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       SchedEntry* fresh = nullptr;
       if (pass == 0 && sched_ok && tiles_x * nb >= kSchedMinTiles)
         if (int rc = schedule_lookup(s, cfg, pt, P, st, &fresh)) return rc;
-      const uint32_t blocks = blocks_for(tiles_x * nb);
-      P.tile_blocks = blocks;
+      const uint32_t tile_blocks = blocks_for(tiles_x * nb);
+      const uint32_t blocks = tile_blocks + (band0 == 0 ? halo_blocks : 0);  // the halo chains ride on the first launch
+      P.tile_blocks = tile_blocks;
       P.level_stride = blocks * kBlock;
       const size_t off = (size_t)row0 * tile->w;
       P.rgb = d_rgb ? d_rgb + 3 * off : nullptr;
@@ -733,12 +796,13 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       if (fresh)
         if (int rc = schedule_finish(s, fresh, tiles_x * nb, st)) return rc;
     }
+    if (literal && stats && pass == 0) P3D_HIP(hipEventRecord(s->ev_mid, st));
   }
   if (literal) {
     // Work-list launches over the whole tile: A (units whose first closest hit changed under the predecessor's pass-1
     // leftover) is rendered again and writes B (successors of units whose own leftover changed); B is checked, and
     // rendered again where needed, into C; whatever is left after that — almost never anything — is iterated to the
-    // fixed point by one persistent workgroup (C -> A -> C ...).
+    // fixed point by one persistent workgroup (C -> D -> C ...).
     P.x0 = tile->x0; P.w = tile->w; P.h = tile->h; P.row0 = 0; P.y0 = tile->y0;
     P.rgb = d_rgb; P.hit_id = d_hit; P.rgb8 = d_rgb8;
     P.sched = nullptr; P.tile_cost = nullptr;
@@ -746,12 +810,13 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     const uint32_t wide = std::max<uint32_t>(1, std::min<uint32_t>(max_threads / kBlock, std::min<uint32_t>(2048, std::max<uint32_t>(64, H.n_units / 1024))));
     for (int round = 0; round < 3; ++round) {
       H.list_in = ho_list[round]; H.n_in = ho_counters + kHoListA + round;
-      H.list_out = ho_list[(round + 1) % 3]; H.n_out = ho_counters + kHoListA + (round + 1) % 3;
+      H.list_out = ho_list[round + 1]; H.n_out = ho_counters + kHoListA + round + 1;
       H.persistent = round == 2 ? 1u : 0u;
+      // round 0 renders unrelated deep pixels: 16 per wave diverge less than 64 (measured: DESIGN.md)
+      H.lanes = round == 0 ? redo_lanes() : kBlock;
       const uint32_t blocks = round == 2 ? 1u : wide;
       P.level_stride = blocks * kBlock;
       P.tile_blocks = blocks;
-      if (round == 2) P3D_HIP(hipMemsetAsync(ho_counters + kHoListA, 0, sizeof(uint32_t), st));  // A was consumed by round 0
       const hipError_t e = launch_literal(2, cfg->antialiasing != 0, lds_scene, false, P, blocks, lds_bytes, st);
       if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("hand-off kernel launch: ") + hipGetErrorString(e));
     }
