@@ -3,16 +3,26 @@
 
 A step = one frame of the workload rendered by the HIP path into HBM-resident buffers
 (+ for N > 1 the RCCL gather of the per-rank stripe buffers to rank 0 and the
-de-interleave into the frame).  Workload at N = 1: BASELINE.json configs[1] =
-balls_low.p3f at 1024x1024, Whitted, MAX_DEPTH 4, BVH.  For N > 1 the frame grows so
-that every GPU keeps 1024*1024 pixels of the same picture (weak scaling; N = 4 is the
-2048x2048 of configs[3]); rows are dealt to ranks in 8-row stripes, round-robin.
+de-interleave into the frame).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|tri100k|cornell_pt]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ...] [--stack-mode literal|per_pixel]
 
-Prints ONE JSON line on rank 0.  `roofline` and `cpu_baseline` follow DESIGN.md §Measurement.
+Workloads
+    N = 1 (default `cfg2`): BASELINE.json configs[1] = balls_low.p3f 1024x1024, Whitted MAX_DEPTH 4, BVH.
+    N > 1 (default `cfg4`): BASELINE.json configs[3] = 100k random triangles 2048x2048, Whitted MAX_DEPTH 6, BVH,
+        the SAME frame whatever N (strong scaling); rows dealt to ranks in 8-row stripes, round-robin; every frame
+        ends with ONE collective that brings float RGB + hit IDs (16 B/px) to rank 0.
+    `cfg2w`: the cfg2 picture weak-scaled (1024*1024 pixels per GPU), u8 image gathered, 8 frames per collective.
+
+`value` is measured with the default p3d_config.stack_mode = P3D_STACK_LITERAL, whose frames are bit-identical to
+the reference's serial pixel order (tests/test_gpu_parity.py); `per_pixel_stack` is the same frame with the stack
+emptied at every primary sample (one launch, <= 1e-4 from the reference on sphere scenes, identical on triangle
+scenes).  Rays are counted as the reference's frame has them (one traversal query each).
+
+Prints ONE JSON line on rank 0.  `roofline` and `cpu_baseline` follow DESIGN.md "Measurement".
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -22,15 +32,22 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: max clock
+SIMDS = 256 * 4        # 256 CUs x 4 SIMDs
+HBM_PEAK_GBPS = 8000.0
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "tri100k", "cornell_pt"],
-                    help="cfg2 (default) = BASELINE configs[1]; cfg3/cfg4/cfg5 = configs[2]/[3]/[4] at their full sizes; "
-                         "tri100k / cornell_pt = the same scenes at quick sizes")
+    ap.add_argument("--workload", default=None,
+                    choices=["cfg1", "cfg2", "cfg2w", "cfg3", "cfg4", "cfg5", "tri100k", "cornell_pt"],
+                    help="default: cfg2 (BASELINE configs[1]) on one GPU, cfg4 (configs[3], strong scaling) on several; "
+                         "cfg3/cfg5 = configs[2]/[4] at their full sizes; cfg2w = cfg2 weak-scaled; tri100k / cornell_pt = quick sizes")
+    ap.add_argument("--stack-mode", default="literal", choices=["literal", "per_pixel"],
+                    help="p3d_config.stack_mode of the timed frames (include/p3d.h)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-order", default="cost", choices=["cost", "frame"],
                     help="p3d_config.tile_order: cost = tiles most-expensive-class first (schedule recorded by the first "
@@ -38,23 +55,26 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production).  gloo stages the gather through host memory: only for "
                          "rehearsing the N>1 code path with several ranks on ONE GPU")
-    ap.add_argument("--gather-batch", type=int, default=8,
-                    help="N > 1: frames rendered back to back into one buffer per collective (every frame still reaches "
-                         "rank 0; a 0.15 ms frame cannot pay for a collective launch of its own)")
-    ap.add_argument("--gather", default="u8", choices=["u8", "f32"],
-                    help="N>1: what rank 0 collects per frame: the u8 image (img_Data, 3 B/px) or float RGB + hit IDs (16 B/px)")
+    ap.add_argument("--gather-batch", type=int, default=None,
+                    help="N > 1: frames rendered back to back into one buffer per collective (default 1; cfg2w: 8 — a "
+                         "0.3 ms frame cannot pay for a collective launch of its own)")
+    ap.add_argument("--gather", default=None, choices=["u8", "f32"],
+                    help="N>1: what rank 0 collects per frame: float RGB + hit IDs (16 B/px, default) or the u8 image (3 B/px, cfg2w default)")
     return ap.parse_args()
 
 
-def workload_setup(name, n_gpus, p3d):
-    """-> (scene path, config, base resolution, description)"""
+def workload_setup(name, p3d):
+    """-> (scene path, config, base resolution (negative: fixed, strong scaling), description)"""
     scenes = os.path.join(ROOT, "tests", "golden", "scenes")
     if name == "cfg1":  # BASELINE configs[0]: the reference's own CPU-runnable case, fixed 512x512
         return (os.path.join(scenes, "balls_low.p3f"), p3d.whitted_config(accel=p3d.ACCEL_NONE, max_depth=1), -512,
                 "balls_low.p3f 512x512, Whitted MAX_DEPTH=1, no acceleration structure (BASELINE configs[0])")
     if name == "cfg2":
+        return (os.path.join(scenes, "balls_low.p3f"), p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4), -1024,
+                "balls_low.p3f 1024x1024, Whitted MAX_DEPTH=4, BVH, no AA (BASELINE configs[1])")
+    if name == "cfg2w":
         return (os.path.join(scenes, "balls_low.p3f"), p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4), 1024,
-                "balls_low.p3f, Whitted MAX_DEPTH=4, BVH, no AA (BASELINE configs[1])")
+                "balls_low.p3f, Whitted MAX_DEPTH=4, BVH, no AA, 1024x1024 pixels per GPU (BASELINE configs[1] weak-scaled)")
     if name in ("tri100k", "cfg4"):
         sys.path.insert(0, os.path.join(ROOT, "scenes"))
         import make_tri100k
@@ -67,17 +87,41 @@ def workload_setup(name, n_gpus, p3d):
         if name == "cfg4":  # BASELINE configs[3]: 2048x2048 whatever the GPU count (strong scaling)
             return (path, p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=6), -2048,
                     "100k random triangles 2048x2048, Whitted MAX_DEPTH=6, BVH (BASELINE configs[3])")
-        return (path, p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=6), 1024,
-                "100k random triangles, Whitted MAX_DEPTH=6, BVH (BASELINE configs[3] scene)")
+        return (path, p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=6), -1024,
+                "100k random triangles 1024x1024, Whitted MAX_DEPTH=6, BVH (BASELINE configs[3] scene)")
     cornell = os.path.join(ROOT, "scenes", "cornell.p3f")
     if name == "cfg3":  # BASELINE configs[2]
-        return (cornell, p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=16, max_depth=20), 1024,
-                "cornell.p3f, path tracer 256 spp, MAX_DEPTH=20, BVH (BASELINE configs[2])")
+        return (cornell, p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=16, max_depth=20), -1024,
+                "cornell.p3f 1024x1024, path tracer 256 spp, MAX_DEPTH=20, BVH (BASELINE configs[2])")
     if name == "cfg5":  # BASELINE configs[4]: thin lens (aperture 10, focal 1), 4096 spp; fixed 1024x1024
         return (cornell, p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=64, max_depth=20, dof=1), -1024,
-                "cornell.p3f aperture 10 focal 1, path tracer 4096 spp + DOF sampler, BVH (BASELINE configs[4])")
+                "cornell.p3f 1024x1024 aperture 10 focal 1, path tracer 4096 spp + DOF sampler, BVH (BASELINE configs[4])")
     return (cornell, p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=4, max_depth=20),
-            512, "cornell.p3f, path tracer 16 spp, BVH (BASELINE configs[2] scene, reduced spp)")
+            -512, "cornell.p3f 512x512, path tracer 16 spp, BVH (BASELINE configs[2] scene, reduced spp)")
+
+
+def kernel_source_hash():
+    """SHA-256 over the device sources: a PMC summary under profiles/ is only quoted for the kernels it was taken from."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "p3d-raytracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hpp", ".inc", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary(workload, stack_mode):
+    """profiles/r02/<workload>_<stack mode>_pmc_summary.json (profiles/r02_profile_recipe.sh) if it was collected
+    from exactly these kernel sources, else None: stale counters are not quoted."""
+    path = os.path.join(ROOT, "profiles", "r02", "%s_%s_pmc_summary.json" % (workload, stack_mode))
+    if not os.path.exists(path):
+        return None, "no PMC summary committed for this workload (%s)" % os.path.relpath(path, ROOT)
+    s = json.load(open(path))
+    if s.get("source_hash") != kernel_source_hash():
+        return None, "PMC summary %s was collected from other kernel sources (%s, now %s)" % (
+            os.path.relpath(path, ROOT), s.get("source_hash"), kernel_source_hash())
+    return s, os.path.relpath(path, ROOT)
 
 
 def main():
@@ -106,8 +150,13 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
     host_staged = world > 1 and args.backend == "gloo"
 
-    scene_path, cfg, base, desc = workload_setup(args.workload, world, p3d)
+    workload = args.workload or ("cfg2" if world == 1 else "cfg4")
+    gather = args.gather or ("u8" if workload == "cfg2w" else "f32")
+    scene_path, cfg, base, desc = workload_setup(workload, p3d)
     cfg.tile_order = p3d.TILE_ORDER_COST if args.tile_order == "cost" else p3d.TILE_ORDER_FRAME
+    cfg.stack_mode = p3d.STACK_LITERAL if args.stack_mode == "literal" else p3d.STACK_PER_PIXEL
+    whitted = cfg.integrator == p3d.WHITTED or not cfg.antialiasing
+    literal = cfg.stack_mode == p3d.STACK_LITERAL and whitted and cfg.accel == p3d.ACCEL_BVH
     stripe_h = 8
     fixed = base < 0  # negative base: fixed frame size (strong scaling)
     base = abs(base)
@@ -115,7 +164,7 @@ def main():
     assert res % (stripe_h * world) == 0
     hs = p3d.HostScene(scene_path)
     hs.set_resolution(res, res)
-    if args.workload == "cfg5":
+    if workload == "cfg5":
         hs.set_lens(10.0, 1.0)
     dev = p3d.DeviceScene(hs, bvh=True, device=dev_index)
     tile = p3d.stripe_tile((res, res), rank, world, stripe_h) if world > 1 else dev.full_tile()
@@ -126,7 +175,7 @@ def main():
     # allocation, 16 B/px) and the gamma-corrected u8 image (img_Data, 3 B/px).  Rank 0 collects one
     # of the two (--gather) for EVERY frame; B = --gather-batch consecutive frames share one
     # collective (their buffers are adjacent), double-buffered against the rendering of the next B.
-    B = max(1, args.gather_batch) if world > 1 else 1
+    B = (args.gather_batch or (8 if workload == "cfg2w" else 1)) if world > 1 else 1
     packed_sz, u8_sz = p3d.packed_bytes(n_local), n_local * 3
 
     def new_bufs():
@@ -137,7 +186,7 @@ def main():
     in_flight = [0, 0]    # frames of the batch a pending gather carries
     sent_seq = [0, 0]     # order in which the slots' collectives were launched
     last_frame = [None]   # (slot, index) of the newest frame assembled on rank 0
-    pick = (lambda pair: pair[1]) if args.gather == "u8" else (lambda pair: pair[0])
+    pick = (lambda pair: pair[1]) if gather == "u8" else (lambda pair: pair[0])
     gdev = "cpu" if host_staged else "cuda"
     # (every rank keeps receive buffers: only rank 0 uses them unless the backend forces all_gather)
     gathered = ([[torch.empty(pick(bufs[0]).shape, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
@@ -147,20 +196,18 @@ def main():
     frame_hit = torch.empty((B, res, res), dtype=torch.int32, device=gdev) if rank == 0 and world > 1 else None
 
     def assemble(slot):
-        if args.gather == "u8":
+        if gather == "u8":
             p3d.assemble_frame8(gathered[slot], (res, res), world, stripe_h, frame8, batch=B)
         else:
             p3d.assemble_frame(gathered[slot], (res, res), world, stripe_h, frame_rgb, frame_hit, batch=B)
         last_frame[0] = in_flight[slot] - 1
 
-    ev_pairs = []
-
-    def render_into(pair, tile_, cfg_, stats=None, frame=0):
+    def render_into(pair, tile_, cfg_, stats=None, frame=0, scene=None):
         packed, u8 = pair
         n_px = tile_.w * tile_.h
-        base = packed.data_ptr() + frame * p3d.packed_bytes(n_px)
-        dev.render_device(cfg_, tile_, d_rgb=base, d_hit=base + n_px * 12, d_rgb8=u8.data_ptr() + frame * n_px * 3,
-                          stream=stream.cuda_stream, stats=stats)
+        base_ = packed.data_ptr() + frame * p3d.packed_bytes(n_px)
+        (scene or dev).render_device(cfg_, tile_, d_rgb=base_, d_hit=base_ + n_px * 12, d_rgb8=u8.data_ptr() + frame * n_px * 3,
+                                     stream=stream.cuda_stream, stats=stats)
 
     def finish(slot):  # the collective of this slot has to be complete before the buffer is reused
         if handles[slot] is not None:
@@ -176,20 +223,11 @@ def main():
             in_flight[slot], filled[slot] = filled[slot], 0
             sent_seq[slot] = max(sent_seq) + 1
 
-    def step(i, timed):
+    def step(i, cfg_):
         slot, f = (i // B) & 1, i % B
         if f == 0:
             finish(slot)
-        # kernel duration for the roofline: HIP events on the launch stream around every 8th timed
-        # step (an event pair costs a few microseconds of stream time, comparable to 3 % of this frame)
-        probe = timed and (i % 8 == 0)
-        if probe:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-        render_into(bufs[slot], tile, cfg, frame=f)
-        if probe:
-            e1.record(stream)
-            ev_pairs.append((e0, e1))
+        render_into(bufs[slot], tile, cfg_, frame=f)
         filled[slot] += 1
         if f == B - 1:
             send(slot)
@@ -208,31 +246,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i, False)
-    drain()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, True)
-    drain()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    def timed_loop(cfg_):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks.  -> seconds"""
+        for i in range(args.warmup):
+            step(i, cfg_)
+        drain()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, cfg_)
+        drain()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
 
-    # counts (deterministic): one counted pass of this rank's tile outside the timed region
+    # the first launch of a (scene, config, tile) key renders in image order and records the tile costs: time it on
+    # its own (cold), before the warm-up that lets every later frame use the recorded schedule
+    # (a 64-row tile first: loads the code objects of every kernel involved without touching the full tile's key)
+    small = p3d.Tile(tile.x0, tile.y0, tile.w, min(tile.h, 64), tile.stripe_h, tile.stripe_stride)
+    render_into(bufs[0], small, cfg, stats=p3d.Stats())
+    cold = p3d.Stats()
+    render_into(bufs[0], tile, cfg, stats=cold)
+    dt = timed_loop(cfg)
+
+    # Launch durations inside the frame, live: HIP events of the library on the launch stream (p3d_stats.kernel_ms /
+    # pass1_ms / handoff_ms), 16 frames after the timed region, smallest and mean.
+    probes = []
+    for _ in range(16):
+        st_ = p3d.Stats()
+        render_into(bufs[0], tile, cfg, stats=st_)
+        probes.append((st_.kernel_ms, st_.pass1_ms, st_.handoff_ms))
+    kernel_ms = sum(p[0] for p in probes) / len(probes)
+    pass1_ms = sum(p[1] for p in probes) / len(probes) if literal else kernel_ms
+    handoff_ms = sum(p[2] for p in probes) / len(probes) if literal else 0.0
+
+    # Rays of the frame as the reference counts them = the queries of the final frame.  The per-pixel-stack launch
+    # traces exactly those (the literal launches trace some of them twice: that is overhead, not throughput).
     cfg_counted = p3d.Config.from_buffer_copy(bytes(cfg))
     cfg_counted.collect_stats = 1
+    cfg_counted.stack_mode = p3d.STACK_PER_PIXEL
     st = p3d.Stats()
     render_into(bufs[0], tile, cfg_counted, stats=st)
     counts = torch.tensor([st.rays, st.algorithmic_bytes()], dtype=torch.float64, device="cpu" if host_staged else "cuda")
     if world > 1:
         dist.all_reduce(counts)
     rays_total, _ = counts.tolist()
+    handoff = None
+    if literal:
+        cfg_counted.stack_mode = p3d.STACK_LITERAL
+        hst = p3d.Stats()
+        render_into(bufs[0], tile, cfg_counted, stats=hst)
+        handoff = {"checked": int(hst.handoff_checked), "redone": int(hst.handoff_redone), "rounds": int(hst.handoff_rounds)}
+
+    # the same frames with the stack emptied at every primary sample (one launch per frame): N = 1 only
+    per_pixel = None
+    if literal and world == 1:
+        cfg_pp = p3d.Config.from_buffer_copy(bytes(cfg))
+        cfg_pp.stack_mode = p3d.STACK_PER_PIXEL
+        pp_cold = p3d.Stats()
+        fresh = p3d.DeviceScene(hs, bvh=True, device=dev_index)
+        render_into(bufs[0], small, cfg_pp, stats=p3d.Stats(), scene=fresh)
+        render_into(bufs[0], tile, cfg_pp, stats=pp_cold, scene=fresh)
+        dt_pp = timed_loop(cfg_pp)
+        pk = []
+        for _ in range(16):
+            st_ = p3d.Stats()
+            render_into(bufs[0], tile, cfg_pp, stats=st_)
+            pk.append(st_.kernel_ms)
+        per_pixel = {"value": round(rays_total * args.steps / dt_pp / 1e6, 1), "ms_per_step": round(dt_pp / args.steps * 1e3, 4),
+                     "kernel_ms": round(sum(pk) / len(pk), 4), "cold_kernel_ms": round(pp_cold.kernel_ms, 4),
+                     "note": "P3D_STACK_PER_PIXEL: hit IDs as the literal frame, colours within 1e-4 of it on this scene"}
 
     gather_check = None
     if world > 1 and rank == 0:
@@ -244,7 +331,7 @@ def main():
         torch.cuda.synchronize()
         ref_packed, ref_u8 = ref_pair[0].to(gdev), ref_pair[1].to(gdev)
         k = last_frame[0]
-        if args.gather == "u8":
+        if gather == "u8":
             ok = bool(torch.equal(frame8[k].reshape(-1), ref_u8))
         else:
             ok = bool(torch.equal(frame_rgb[k].reshape(-1).view(torch.int32), ref_packed[: res * res * 12].view(torch.int32))
@@ -254,19 +341,32 @@ def main():
     if rank == 0:
         value = rays_total * args.steps / dt / 1e6
         alg_bytes_launch = st.algorithmic_bytes()  # rank 0's launch
-        achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm_bytes.json")
-        if os.path.exists(prof) and args.workload == "cfg2" and world == 1:
-            traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-        valu = None
-        pmc = os.path.join(ROOT, "profiles", "r01", "cfg2_pmc_summary.json")
-        if os.path.exists(pmc) and args.workload == "cfg2" and world == 1 and kernel_ms > 0:
-            # the ceiling that does apply: a wave64 VALU instruction holds its SIMD for
-            # 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz; instruction count from the committed PMC pass
-            insts = json.load(open(pmc))["SQ_INSTS_VALU"]["mean"]
-            floor_ms = insts * 4 / (1024 * 2.4e9) * 1e3
-            valu = {"wave_instructions": int(insts), "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / kernel_ms, 4)}
+        dominant = "whitted_kernel" if whitted else "pt_kernel"
+        dom_ms = pass1_ms if literal else kernel_ms
+        alg_gbps = alg_bytes_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # The ceiling that applies (DESIGN.md "Measurement"): the scene is LDS- or L2-resident, so HBM serves the
+        # framebuffer only.  What bounds the dominant kernel is instruction issue: a wave64 VALU instruction holds its
+        # SIMD for 4 cycles, 1024 SIMDs at 2.4 GHz.  Instruction and HBM byte counts come from the rocprofv3 PMC passes
+        # of this workload committed under profiles/r02/ — quoted only if taken from exactly these kernel sources.
+        summary, src = pmc_summary(workload, args.stack_mode) if world == 1 else (None, "PMC summaries are per single-GPU workload")
+        roof = {"kernel": dominant, "kernel_ms": round(dom_ms, 4),
+                "algorithmic": {"bytes_per_launch": int(alg_bytes_launch), "GBps": round(alg_gbps, 1),
+                                "note": "SURVEY.md 8(d) definition; served by LDS/L2, not by HBM, so not a fraction of anything"}}
+        if summary:
+            k = summary["dominant"]
+            insts = k["SQ_INSTS_VALU"]
+            achieved = insts / (dom_ms * 1e-3) / 1e9  # G wave-instructions / s
+            peak = SIMDS * CLOCK_HZ / 4 / 1e9
+            traffic = k.get("hbm_bytes")
+            roof.update({"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "Gwave-instr/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "hbm": {"achieved_GBps": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None, "peak_GBps": HBM_PEAK_GBPS,
+                                 "frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None},
+                         "wave_instructions_valu": int(insts), "lane_utilisation": k.get("lane_utilisation"),
+                         "rocprof_avg_ms": k.get("avg_ms"), "source": src})
+        else:
+            roof.update({"bound": "valu_issue", "achieved": None, "peak": round(SIMDS * CLOCK_HZ / 4 / 1e9, 1), "unit": "Gwave-instr/s",
+                         "frac": None, "traffic": None, "source": src})
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -274,28 +374,43 @@ def main():
             "scaling": "strong" if fixed else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "resolution": [res, res], "rays_per_frame": int(rays_total),
-                       "ray_definition": "one traversal query (closest-hit or any-hit)",
+                       "ray_definition": "one traversal query (closest-hit or any-hit) of the frame as the reference renders it",
+                       "stack_mode": args.stack_mode if whitted and cfg.accel == p3d.ACCEL_BVH else "n/a (no stack survives a query here)",
                        "outputs_per_rank": "float RGB + hit ID (16 B/px) + u8 image (3 B/px), all written to HBM",
                        "tile_order": args.tile_order,
                        "parallelism": "image rows in %d-row stripes, round-robin over %d GPU(s)%s"
                                       % (stripe_h, world,
-                                         "; every frame's %s gathered to rank 0 over RCCL, %d frames per collective, "
+                                         "; every frame's %s gathered to rank 0 over %s, %d frame(s) per collective, "
                                          "double-buffered; gathered frame vs single-GPU frame: %s"
-                                         % ("u8 image" if args.gather == "u8" else "float RGB + hit IDs", B, gather_check)
+                                         % ("u8 image" if gather == "u8" else "float RGB + hit IDs", "RCCL" if args.backend == "nccl" else "gloo (host-staged)", B, gather_check)
                                          if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-                         "kernel": "whitted_kernel" if cfg.integrator == p3d.WHITTED or not cfg.antialiasing else "pt_kernel",
-                         "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes_launch),
-                         "valu_issue": valu,
-                         "note": "algorithmic bytes (DESIGN.md) are served from LDS/L2, not HBM: the kernel is "
-                                 "VALU/latency bound; traffic = measured HBM bytes"},
+            "frame": {"kernel_ms": round(kernel_ms, 4), "pass1_ms": round(pass1_ms, 4), "handoff_ms": round(handoff_ms, 4),
+                      "cold_kernel_ms": round(cold.kernel_ms, 4), "handoff": handoff,
+                      "note": "HIP events of the library on the launch stream; cold = first launch of this scene and config "
+                              "(image order, tile costs recorded), the timed frames use the recorded tile schedule"},
+            "roofline": roof,
         }
+        if per_pixel:
+            out["per_pixel_stack"] = per_pixel
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.workload, scene_path, cfg, res)
+            out["cpu_baseline"] = cpu_baseline(workload, scene_path, cfg, res)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def one_socket_cpus():
+    """CPUs of the socket this process may run on (affinity mask of the all-cores leg)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    by_pkg = {}
+    for c in allowed:
+        try:
+            pkg = int(open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % c).read())
+        except OSError:
+            pkg = 0
+        by_pkg.setdefault(pkg, []).append(c)
+    pkg = min(by_pkg)
+    return pkg, by_pkg[pkg], len(by_pkg)
 
 
 def cpu_baseline(workload, scene_path, cfg, res):
@@ -329,13 +444,24 @@ def cpu_baseline(workload, scene_path, cfg, res):
         if best is None or st.seconds < best:
             best, rays = st.seconds, st.rays
     out = {"value": round(rays / best / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample}
-    # all host cores (rows dealt round-robin), parallel semantics; informational
-    n = os.cpu_count() or 1
-    ocfg.stack_mode = 0
-    ocfg.trace_zero_weight = 0
-    ocfg.threads = n
-    _, _, st = sc.render(ocfg, x0, y0, w, h)
-    out["all_cores"] = {"value": round(st.rays / st.seconds / 1e6, 3), "cores": n}
+    # all cores of ONE socket (rows dealt round-robin over that many threads, pinned to the socket; per-pixel stack —
+    # the reference's serial stack cannot be threaded), best of 3; informational
+    pkg, cpus, n_pkgs = one_socket_cpus()
+    old = os.sched_getaffinity(0)
+    try:
+        os.sched_setaffinity(0, cpus)
+        ocfg.stack_mode = 0
+        ocfg.trace_zero_weight = 0
+        ocfg.threads = len(cpus)
+        best = None
+        for _ in range(3):
+            _, _, st = sc.render(ocfg, x0, y0, w, h)
+            if best is None or st.seconds < best[0]:
+                best = (st.seconds, st.rays)
+    finally:
+        os.sched_setaffinity(0, old)
+    out["one_socket"] = {"value": round(best[1] / best[0] / 1e6, 3), "cores": len(cpus), "socket": pkg, "sockets_on_host": n_pkgs,
+                         "sample": "same sample, best of 3, threads pinned to the logical CPUs of one socket"}
     return out
 
 
