@@ -202,6 +202,20 @@ typedef struct p3d_scene_desc {
 #define P3D_STACK_LITERAL 0u
 #define P3D_STACK_PER_PIXEL 1u
 
+/*
+ * How the chain of rayTracing calls of a pixel (main.cpp:247-300) is put on the GPU.  MEGAKERNEL: one lane follows its
+ * pixel from the primary ray to the end of the chain.  PER_LEVEL: one launch per chain level; the surviving child rays
+ * are compacted into a queue and put in order (origin cell, direction octant) between levels, so that every wave of a
+ * reflection level starts with 64 live rays.  Only for Whitted frames without anti-aliasing over a BVH too big for LDS.
+ * AUTO (default) = MEGAKERNEL: on the scenes measured the per-level launches issue 13 % fewer instructions but take
+ * longer (100k triangles 2048x2048: 25.3 ms against 19.6 ms) — what keeps lanes idle there is the spread of traversal
+ * lengths inside one query, not dead pixels.  Same queries in the same per-pixel order either way: the
+ * frames are bit-identical.
+ */
+#define P3D_CHAIN_AUTO 0u
+#define P3D_CHAIN_MEGAKERNEL 1u
+#define P3D_CHAIN_PER_LEVEL 2u
+
 typedef struct p3d_config {
   uint32_t integrator;    /* PATHTRACING        constants.h:36  */
   uint32_t accel;         /* acl_str            constants.h:44  */
@@ -221,7 +235,7 @@ typedef struct p3d_config {
   uint64_t seed;          /* replaces set_rand_seed(time*time), main.cpp:722:
                              every (pixel, sample) draws from its own stream */
   uint32_t stack_mode;    /* P3D_STACK_*: BVH::hit_stack across pixels (bvh.cpp:86) */
-  uint32_t reserved;
+  uint32_t chain_launch;  /* P3D_CHAIN_*: how the reflect / refract chain is launched; never changes a result */
 } p3d_config;
 
 /*
@@ -348,13 +362,27 @@ int p3d_debug_set_trip_bound(uint32_t trips);
  * (bvh.cpp:278), Grid::Traverse(ray) (grid.cpp:154) and main.cpp:208-216 for any
  * hit.  Every ray starts with an empty traversal stack.  Host buffers:
  *   origin, direction : n*3 float (direction used as given, not normalised)
- *   hit_id : n int32 (-1 = miss) ; t : n float ; hit_point : n*3 float (may be NULL)
+ *   hit_id : n int32 (-1 = miss) ; t : n float, the traversal's tmin / min_t (bvh.cpp:246, grid.cpp:100,
+ *   main.cpp:120), FLT_MAX on a miss (may be NULL) ; hit_point : n*3 float (may be NULL)
  *   occluded : n uint8
  */
 int p3d_trace_closest(p3d_scene* scene, uint32_t accel, uint32_t n, const float* origin,
                       const float* direction, int32_t* hit_id, float* t, float* hit_point);
 int p3d_trace_any(p3d_scene* scene, uint32_t accel, uint32_t n, const float* origin,
                   const float* direction, uint8_t* occluded);
+/*
+ * Per-object queries — device counterparts of the virtual Object::intercepts(Ray&, float&)
+ * (scene.cpp:47-94,116-137,149-186,215-227) and Object::getNormal(Vector) (scene.cpp:41-44,
+ * 139-142,188-192,229-267) for object `object` (index in Scene::objects) and n rays / points.
+ *   direction : n*3 float, IN and OUT — Sphere::intercepts normalises the ray in place
+ *               (scene.cpp:156, ray.h:16-18); the other kinds leave it as it was
+ *   hit : n uint8 ; t : n float (written where hit, as the reference writes its out-parameter)
+ */
+int p3d_object_intercepts(p3d_scene* scene, uint32_t object, uint32_t n, const float* origin,
+                          float* direction, uint8_t* hit, float* t);
+int p3d_object_normal(p3d_scene* scene, uint32_t object, uint32_t n, const float* point, float* normal);
+/* Scene::GetSkyboxColor (scene.cpp:379-457) for n ray directions: rgb n*3 float.  Needs p3d_scene_set_skybox. */
+int p3d_skybox_color(p3d_scene* scene, uint32_t n, const float* direction, float* rgb);
 
 /* ---- host side: .p3f loader and acceleration-structure builders ---- */
 /*
@@ -382,6 +410,10 @@ int p3d_host_scene_replicate_lights(p3d_host_scene* hs, uint32_t spp_sqrt, float
  * pointer stays valid until the host scene is destroyed or modified. */
 int p3d_host_scene_desc(p3d_host_scene* hs, int build_bvh, int build_grid,
                         const p3d_scene_desc** out);
+/* Points the query methods of the host classes (C++: Object::intercepts / getNormal, BVH::intersect_bvh /
+ * bool_intersect_bvh, Grid::Traverse, Scene::GetSkyboxColor — p3d-raytracer_amd/host/scene_model.hpp) at the
+ * device scene created from this host scene's descriptor; they forward one query per call.  NULL unbinds. */
+int p3d_host_scene_bind_device(p3d_host_scene* hs, p3d_scene* scene);
 
 #ifdef __cplusplus
 }

@@ -273,6 +273,13 @@ class Scene:
         h = self._L.orc_object_intercepts(self.h, obj, _fp(o), _fp(d), C.byref(t))
         return bool(h), t.value, d
 
+    def skybox_color(self, d):
+        d = np.array(d, np.float32)
+        c = np.zeros(3, np.float32)
+        if self._L.orc_skybox_color(self.h, _fp(d), _fp(c)) != 0:
+            raise RuntimeError("no skybox loaded")
+        return c
+
     def object_normal(self, obj, p):
         p = np.array(p, np.float32)
         n = np.zeros(3, np.float32)

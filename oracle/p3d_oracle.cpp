@@ -644,7 +644,7 @@ struct Ctx {
 };
 
 // bvh.cpp:198-276 — closest hit; the ray is a BY-VALUE copy.
-bool intersect_bvh(Ctx& cx, Ray ray, int* hit_obj, V3& hit_point) {
+bool intersect_bvh(Ctx& cx, Ray ray, int* hit_obj, V3& hit_point, float* t_out = nullptr) {
   const Bvh& B = cx.sc->bvh;
   const std::vector<Object>& O = cx.sc->objects;
   float tmp, tmin = FLT_MAX;
@@ -689,6 +689,7 @@ bool intersect_bvh(Ctx& cx, Ray ray, int* hit_obj, V3& hit_point) {
     if (changed) continue;
     if (cx.hit_stack.empty()) {
       if (hit) hit_point = ray.d * tmin + ray.o;  // bvh.cpp:271 (the copy's current direction)
+      if (t_out) *t_out = tmin;
       return hit;
     }
   }
@@ -782,7 +783,7 @@ bool grid_init_traverse(const Grid& G, Ray& ray, GridWalk& k) {
 }
 
 // grid.cpp:71-151 — closest hit; the ray is taken BY REFERENCE (caller sees Q8 mutation).
-bool grid_traverse(Ctx& cx, Ray& ray, int* hitobject, V3& hitpoint) {
+bool grid_traverse(Ctx& cx, Ray& ray, int* hitobject, V3& hitpoint, float* t_out = nullptr) {
   const Grid& G = cx.sc->grid;
   const std::vector<Object>& O = cx.sc->objects;
   GridWalk k;
@@ -798,19 +799,19 @@ bool grid_traverse(Ctx& cx, Ray& ray, int* hitobject, V3& hitpoint) {
     }
     if (k.tx_next < k.ty_next && k.tx_next < k.tz_next) {
       if (min_obj >= 0 && (double)min_t < k.tx_next) {
-        *hitobject = min_obj; hitpoint = ray.o + ray.d * min_t; return true;
+        *hitobject = min_obj; hitpoint = ray.o + ray.d * min_t; if (t_out) *t_out = min_t; return true;
       }
       k.tx_next += k.dtx; k.ix += k.ix_step;
       if (k.ix == k.ix_stop) return false;
     } else if (k.ty_next < k.tz_next) {
       if (min_obj >= 0 && (double)min_t < k.ty_next) {
-        *hitobject = min_obj; hitpoint = ray.o + ray.d * min_t; return true;
+        *hitobject = min_obj; hitpoint = ray.o + ray.d * min_t; if (t_out) *t_out = min_t; return true;
       }
       k.ty_next += k.dty; k.iy += k.iy_step;
       if (k.iy == k.iy_stop) return false;
     } else {
       if (min_obj >= 0 && (double)min_t < k.tz_next) {
-        *hitobject = min_obj; hitpoint = ray.o + ray.d * min_t; return true;
+        *hitobject = min_obj; hitpoint = ray.o + ray.d * min_t; if (t_out) *t_out = min_t; return true;
       }
       k.tz_next += k.dtz; k.iz += k.iz_step;
       if (k.iz == k.iz_stop) return false;
@@ -851,9 +852,9 @@ int closest_hit(Ctx& cx, Ray& ray, float& min_t, V3& hit_p) {
   float t = FLT_MAX;
   min_t = FLT_MAX;
   if (cx.cfg.accel == 1) {
-    if (!grid_traverse(cx, ray, &min_obj, hit_p)) min_obj = -1;
+    if (!grid_traverse(cx, ray, &min_obj, hit_p, &min_t)) min_obj = -1;
   } else if (cx.cfg.accel == 2) {
-    if (!intersect_bvh(cx, ray, &min_obj, hit_p)) min_obj = -1;
+    if (!intersect_bvh(cx, ray, &min_obj, hit_p, &min_t)) min_obj = -1;
   } else {
     for (int i = 0; i < (int)S.objects.size(); i++) {
       if (intercepts(S.objects[i], ray, t, cx.st) && (t < min_t)) { min_obj = i; min_t = t; }
@@ -1686,7 +1687,7 @@ int orc_trace_closest(void* s, int accel, int n, const float* o, const float* d,
     if (obj >= 0 && accel == 0) hp = r.o + r.d * min_t;  // main.cpp:164
     hit[i] = obj;
     if (obj < 0) { hp = v3(0, 0, 0); min_t = FLT_MAX; }
-    if (t) t[i] = (accel == 0) ? min_t : 0.0f;  // BVH/grid return only the hit point
+    if (t) t[i] = min_t;  // the traversal's tmin / min_t (bvh.cpp:246, grid.cpp:100, main.cpp:120); FLT_MAX on a miss
     if (hit_point) { hit_point[3 * i] = hp.x; hit_point[3 * i + 1] = hp.y; hit_point[3 * i + 2] = hp.z; }
   }
   return 0;
@@ -1717,6 +1718,17 @@ int orc_trace_any(void* s, int accel, int n, const float* o, const float* d, uin
     }
     occluded[i] = occ;
   }
+  return 0;
+}
+
+int orc_skybox_color(void* s, const float* d3, float* rgb3) {  // scene.cpp:379-457
+  Scene* S = (Scene*)s;
+  if (!S->sky_loaded) return -1;
+  Ray r;
+  r.o = v3(0, 0, 0);
+  r.d = v3(d3[0], d3[1], d3[2]);
+  C3 c = get_skybox_color(*S, r);
+  rgb3[0] = c.r; rgb3[1] = c.g; rgb3[2] = c.b;
   return 0;
 }
 

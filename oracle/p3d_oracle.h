@@ -104,6 +104,7 @@ int orc_primary_ray_lens(void* s, float lx, float ly, float px, float py, float*
 int orc_trace_closest(void* s, int accel, int n, const float* o, const float* d, int32_t* hit,
                       float* t, float* hit_point);
 int orc_trace_any(void* s, int accel, int n, const float* o, const float* d, uint8_t* occluded);
+int orc_skybox_color(void* s, const float* d3, float* rgb3); /* Scene::GetSkyboxColor, scene.cpp:379-457 */
 /* L0 restatements (vector.cpp, ray.h:16-18, camera.h:34-115, maths.h:67-92, sampler.cpp:5-11, color.h:39-44) */
 void orc_vec_normalize(float* v3);
 float orc_vec_length(const float* v3);

@@ -24,16 +24,17 @@ ACCEL_NONE, ACCEL_GRID, ACCEL_BVH = 0, 1, 2
 WHITTED, PATHTRACE = 0, 1
 TILE_ORDER_COST, TILE_ORDER_FRAME = 0, 1
 STACK_LITERAL, STACK_PER_PIXEL = 0, 1
+CHAIN_AUTO, CHAIN_MEGAKERNEL, CHAIN_PER_LEVEL = 0, 1, 2
 SAMPLE_JITTER, SAMPLE_TENT = 0, 1
 LOAD_LEGACY_F11 = 1
 
 EXPORTS = [
     "p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_config_default",
     "p3d_scene_create", "p3d_scene_create_device_bvh", "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_render_tile", "p3d_render_tile_device",
-    "p3d_scene_status", "p3d_debug_set_trip_bound",
+    "p3d_scene_status", "p3d_debug_set_trip_bound", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
     "p3d_trace_closest", "p3d_trace_any", "p3d_host_scene_load", "p3d_host_scene_destroy",
     "p3d_host_scene_set_resolution", "p3d_host_scene_set_lens", "p3d_host_scene_replicate_lights",
-    "p3d_host_scene_desc",
+    "p3d_host_scene_desc", "p3d_host_scene_bind_device",
 ]
 
 
@@ -93,7 +94,7 @@ class Config(C.Structure):
                 ("sample_disk", C.c_uint32), ("soft_shadows", C.c_uint32), ("sample_mode", C.c_uint32),
                 ("light_side", C.c_float), ("gamma", C.c_float), ("collect_stats", C.c_uint32),
                 ("skybox", C.c_uint32), ("tile_order", C.c_uint32), ("seed", C.c_uint64),
-                ("stack_mode", C.c_uint32), ("reserved", C.c_uint32)]
+                ("stack_mode", C.c_uint32), ("chain_launch", C.c_uint32)]
 
 
 class SkyboxFace(C.Structure):
@@ -173,6 +174,11 @@ def lib():
         L.p3d_trace_closest.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
         L.p3d_trace_any.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.p3d_object_intercepts.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.p3d_object_normal.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.p3d_skybox_color.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.p3d_scene_status.argtypes = [C.c_void_p]
+        L.p3d_debug_set_trip_bound.argtypes = [C.c_uint32]
         _lib = L
     return _lib
 
@@ -355,15 +361,39 @@ class DeviceScene:
                                               C.c_void_p(d_hit or None), C.c_void_p(d_rgb8 or None),
                                               C.c_void_p(stream or None), C.byref(stats) if stats is not None else None))
 
-    def trace_closest(self, accel, origin, direction):
+    def trace_closest(self, accel, origin, direction, want_t=False):
         o = np.ascontiguousarray(origin, np.float32)
         d = np.ascontiguousarray(direction, np.float32)
         n = o.shape[0]
         hit = np.zeros(n, np.int32)
         hp = np.zeros((n, 3), np.float32)
-        _check(self._L.p3d_trace_closest(self._h, int(accel), n, o.ctypes.data, d.ctypes.data, hit.ctypes.data, None,
-                                         hp.ctypes.data))
-        return hit, hp
+        t = np.zeros(n, np.float32) if want_t else None
+        _check(self._L.p3d_trace_closest(self._h, int(accel), n, o.ctypes.data, d.ctypes.data, hit.ctypes.data,
+                                         t.ctypes.data if want_t else None, hp.ctypes.data))
+        return (hit, hp, t) if want_t else (hit, hp)
+
+    def object_intercepts(self, obj, origin, direction):
+        """Object::intercepts for n rays: -> (hit, t, direction as the test left it)."""
+        o = np.ascontiguousarray(origin, np.float32)
+        d = np.array(direction, np.float32, order="C")
+        n = o.shape[0]
+        hit = np.zeros(n, np.uint8)
+        t = np.zeros(n, np.float32)
+        _check(self._L.p3d_object_intercepts(self._h, int(obj), n, C.c_void_p(o.ctypes.data), C.c_void_p(d.ctypes.data),
+                                             C.c_void_p(hit.ctypes.data), C.c_void_p(t.ctypes.data)))
+        return hit.astype(bool), t, d
+
+    def object_normal(self, obj, points):
+        p = np.ascontiguousarray(points, np.float32)
+        out = np.zeros_like(p)
+        _check(self._L.p3d_object_normal(self._h, int(obj), p.shape[0], C.c_void_p(p.ctypes.data), C.c_void_p(out.ctypes.data)))
+        return out
+
+    def skybox_color(self, directions):
+        d = np.ascontiguousarray(directions, np.float32)
+        out = np.zeros_like(d)
+        _check(self._L.p3d_skybox_color(self._h, d.shape[0], C.c_void_p(d.ctypes.data), C.c_void_p(out.ctypes.data)))
+        return out
 
     def trace_any(self, accel, origin, direction):
         o = np.ascontiguousarray(origin, np.float32)

@@ -422,7 +422,7 @@ __device__ __forceinline__ bool pop_closer(Stack& st, float tmin, uint32_t& desc
 // and left it empty; a ray that fails it returns with the stack exactly as it found it.
 template <bool SPILL, class CT>
 __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_point, Geom& hit_geom, CT& ct,
-                           bool* root_passed = nullptr) {
+                           bool* root_passed = nullptr, float* t_out = nullptr) {
   float tmp, tmin = FLT_MAX;
   int hit = -1;
   const NodeRec root = load_node(sc.nodes, 0);
@@ -467,6 +467,7 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
     }
   }
   if (hit >= 0) hit_point = ray.d * tmin + ray.o;
+  if (t_out) *t_out = tmin;
   return hit;
 }
 
@@ -616,7 +617,7 @@ __device__ __forceinline__ bool grid_step(GridWalk& k, double& limit) {
 
 // grid.cpp:71-151: the caller's ray (Ray&) is tested and mutated; hit point = o + d*min_t
 template <class CT>
-__device__ int grid_closest(const DevScene& sc, RayS& ray, F3& hit_point, Geom& hit_geom, CT& ct) {
+__device__ int grid_closest(const DevScene& sc, RayS& ray, F3& hit_point, Geom& hit_geom, CT& ct, float* t_out = nullptr) {
   const DevGrid& G = sc.grid;
   GridWalk k;
   if (!grid_init(G, ray, k)) return -1;
@@ -639,6 +640,7 @@ __device__ int grid_closest(const DevScene& sc, RayS& ray, F3& hit_point, Geom& 
     const bool more = grid_step(k, limit);
     if (min_obj >= 0 && (double)min_t < limit) {
       hit_point = ray.o + ray.d * min_t;
+      if (t_out) *t_out = min_t;
       return min_obj;
     }
     if (!more) return -1;
@@ -671,16 +673,17 @@ __device__ bool grid_any(const DevScene& sc, RayS& ray, CT& ct) {
 // ---------------------------------------------------------------------------
 template <int ACCEL, bool SPILL, class CT>
 __device__ __forceinline__ int closest_hit(const DevScene& sc, Stack& st, RayS& ray, F3& P, Geom& g, CT& ct,
-                                           bool* root_passed = nullptr) {
+                                           bool* root_passed = nullptr, float* t_out = nullptr) {
   if (ACCEL == P3D_ACCEL_BVH) {
-    const int slot = bvh_closest<SPILL>(sc, st, ray, P, g, ct, root_passed);
+    const int slot = bvh_closest<SPILL>(sc, st, ray, P, g, ct, root_passed, t_out);
     return slot < 0 ? -1 : (int)geom_object(g);
   } else if (ACCEL == P3D_ACCEL_GRID) {
-    return grid_closest(sc, ray, P, g, ct);
+    return grid_closest(sc, ray, P, g, ct, t_out);
   } else {
     float min_t;
     const int obj = brute_closest(sc, ray, min_t, g, ct);
     if (obj >= 0) P = ray.o + ray.d * min_t;
+    if (t_out) *t_out = min_t;
     return obj;
   }
 }

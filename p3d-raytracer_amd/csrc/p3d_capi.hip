@@ -81,6 +81,7 @@ struct SchedEntry {
            w == o.w && h == o.h && stripe_h == o.stripe_h && stripe_stride == o.stripe_stride;
   }
 };
+constexpr uint32_t kWfHistWords = kWfBins + 32;  // bin counts of one level + the total, padded to a 128-byte multiple
 #ifndef P3D_REDO_LANES
 #define P3D_REDO_LANES 16
 #endif
@@ -115,10 +116,11 @@ struct p3d_scene {
   bool has_bvh = false, has_grid = false;
   uint32_t bvh_max_depth = 0;
   float device_bvh_ms = 0;  // GPU time of lbvh::build, 0 for an uploaded tree
-  Scratch levels, spill, deferred, out_rgb, out_hit, out_rgb8, q_in, q_out;
+  Scratch levels, spill, deferred, wf_rays, wf_keys, wf_sorted, wf_final, out_rgb, out_hit, out_rgb8, q_in, q_out;
   // P3D_STACK_LITERAL (csrc/handoff.hpp): leftovers, per-unit records, work lists, counters
   Scratch ho_entries, ho_meta, ho_first, ho_first_sample, ho_touched, ho_lists, ho_counters, ho_row_chain, ho_halo_pix;
   std::vector<int32_t> ho_chain_key;     // tile the row_chain flags on the device were computed for
+  float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};  // box of BVH node 0 (bins of the per-level ray queue)
   bool zero_weight_reflections = false;  // some material is transmissive AND reflective (main.cpp:282,290-300)
   unsigned long long* d_stats = nullptr;
   uint32_t* d_status = nullptr;          // kHoErr* bits raised by kernels; read and cleared by check_status()
@@ -148,7 +150,7 @@ void p3d_scene_destroy(p3d_scene* s) {
     e.sched.release();
     if (e.ready) (void)hipEventDestroy(e.ready);
   }
-  s->levels.release(); s->spill.release(); s->deferred.release(); s->out_rgb.release(); s->out_hit.release();
+  s->levels.release(); s->spill.release(); s->deferred.release(); s->wf_rays.release(); s->wf_keys.release(); s->wf_sorted.release(); s->wf_final.release(); s->out_rgb.release(); s->out_hit.release();
   s->ho_entries.release(); s->ho_meta.release(); s->ho_first.release(); s->ho_first_sample.release(); s->ho_touched.release();
   s->ho_lists.release(); s->ho_counters.release(); s->ho_row_chain.release(); s->ho_halo_pix.release();
   if (s->d_status) (void)hipFree(s->d_status);
@@ -336,6 +338,12 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
     }
   }
   if (!device_bvh) s->bvh_max_depth = std::max(d->bvh_max_depth, real_depth);
+  if (s->has_bvh) {  // root box, from the node array as uploaded or built
+    float4 root[2];
+    P3D_HIP(hipMemcpy(root, s->d_blob + s->off_nodes, sizeof(root), hipMemcpyDeviceToHost));
+    s->root_min[0] = root[0].x; s->root_min[1] = root[0].y; s->root_min[2] = root[0].z;
+    s->root_max[0] = root[1].x; s->root_max[1] = root[1].y; s->root_max[2] = root[1].z;
+  }
   if (d->has_grid) {
     const p3d_grid_desc& g = d->grid;
     P3D_HIP(hipMalloc((void**)&s->d_cell_start, (size_t)(g.n_cells + 1) * 4));
@@ -575,6 +583,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   if (cfg->integrator > P3D_PATHTRACE || cfg->sample_mode > P3D_SAMPLE_TENT) return fail(P3D_ERR_INVALID, "bad integrator / sample_mode");
   if (cfg->tile_order > P3D_TILE_ORDER_FRAME) return fail(P3D_ERR_INVALID, "bad tile_order");
   if (cfg->stack_mode > P3D_STACK_PER_PIXEL) return fail(P3D_ERR_INVALID, "bad stack_mode");
+  if (cfg->chain_launch > P3D_CHAIN_PER_LEVEL) return fail(P3D_ERR_INVALID, "bad chain_launch");
   if (cfg->max_depth < 0 || cfg->max_depth > 1024) return fail(P3D_ERR_INVALID, "max_depth out of range");
   if (cfg->antialiasing && (cfg->spp_sqrt == 0 || cfg->spp_sqrt > 1024)) return fail(P3D_ERR_INVALID, "spp_sqrt out of range");
   if (cfg->soft_shadows && !cfg->antialiasing)
@@ -639,13 +648,30 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // or the path tracer's two deferred dielectric branches
   const uint32_t levels = pt ? 2 * 3 : (uint32_t)cfg->max_depth;
   const uint32_t deferred = (literal && s->zero_weight_reflections) ? 2u * (uint32_t)std::max(cfg->max_depth, 1) : 0u;
-  const size_t scratch_per_thread = (size_t)(levels + deferred) * sizeof(float4) + (size_t)spill_entries * sizeof(uint2);
-  const uint32_t launch_threads = (uint32_t)std::min<size_t>(kMaxLaunchThreads, kLaunchScratchBudget / std::max<size_t>(scratch_per_thread, 1));
+  // One launch per chain level (wf_level_kernel) where the lanes of a megakernel wave die off in the reflection levels:
+  // Whitted without anti-aliasing over a BVH read from L2.  Not for the zero-weight reflection rays of LITERAL frames
+  // (they make the chain a tree) and not for a grid or the object loop (no stack record to carry between launches).
+  bool per_level = !pt && !cfg->antialiasing && cfg->accel == P3D_ACCEL_BVH && !lds_scene && cfg->max_depth >= 1 && cfg->max_depth <= 64 &&
+                   !(literal && s->zero_weight_reflections) && cfg->chain_launch == P3D_CHAIN_PER_LEVEL && tp == 8;
+  if (cfg->chain_launch == P3D_CHAIN_PER_LEVEL && !per_level)
+    return fail(P3D_ERR_UNSUPPORTED, "chain_launch = PER_LEVEL needs Whitted without anti-aliasing over a BVH too big for LDS (and no transmissive + reflective material under P3D_STACK_LITERAL)");
+  // per-level launches keep their level records per pixel, not per launch thread
+  size_t scratch_per_thread = (size_t)((per_level ? 0 : levels) + deferred) * sizeof(float4) + (size_t)spill_entries * sizeof(uint2);
+  const uint32_t launch_threads = (uint32_t)std::min<size_t>(per_level ? (1u << 23) : kMaxLaunchThreads, kLaunchScratchBudget / std::max<size_t>(scratch_per_thread, 1));
   uint32_t bands_per_launch = std::max<uint32_t>(1, launch_threads / (tiles_x * kBlock));
   const uint32_t total_bands = ((uint32_t)tile->h + tp - 1) / tp;
   if (tile->stripe_h > 0 && sh % (int)tp == 0 && bands_per_launch >= (uint32_t)sh / tp)
     bands_per_launch = (bands_per_launch / ((uint32_t)sh / tp)) * ((uint32_t)sh / tp);  // chunks start on a stripe boundary
   bands_per_launch = std::min(bands_per_launch, total_bands);
+  if (per_level && bands_per_launch < total_bands) {  // the per-level path renders the tile in one go
+    if (cfg->chain_launch == P3D_CHAIN_PER_LEVEL) return fail(P3D_ERR_CAPACITY, "chain_launch = PER_LEVEL: tile too large for one launch");
+    per_level = false;
+    scratch_per_thread += (size_t)levels * sizeof(float4);
+    const uint32_t lt = (uint32_t)std::min<size_t>(kMaxLaunchThreads, kLaunchScratchBudget / std::max<size_t>(scratch_per_thread, 1));
+    bands_per_launch = std::min(std::max<uint32_t>(1, lt / (tiles_x * kBlock)), total_bands);
+    if (tile->stripe_h > 0 && sh % (int)tp == 0 && bands_per_launch >= (uint32_t)sh / tp)
+      bands_per_launch = (bands_per_launch / ((uint32_t)sh / tp)) * ((uint32_t)sh / tp);
+  }
   const uint32_t xcd_chunk = lds_scene ? 1u : tiles_x;
   auto blocks_for = [&](uint32_t ntiles) {  // grid covering ntiles under the chunked XCD map
     const uint32_t groups = (ntiles + 8 * xcd_chunk - 1) / (8 * xcd_chunk);
@@ -657,7 +683,8 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // LITERAL: workgroups behind the tile grid of the first launch render the halo chains (8 chains of 8 pixels per wave)
   const uint32_t halo_blocks_max = literal ? ((uint32_t)tile->h * kHaloChain + kBlock - 1) / kBlock : 0;
   const uint32_t max_threads = (blocks_for(tiles_x * bands_per_launch) + halo_blocks_max) * kBlock;
-  if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * max_threads * sizeof(float4)))) return rc;
+  const size_t tile_units = (size_t)tile->h * ((size_t)tile->w + kHaloChain);  // upper bound of H.n_units
+  if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * (per_level ? tile_units : (size_t)max_threads) * sizeof(float4)))) return rc;
   if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)spill_entries * max_threads * sizeof(uint2)))) return rc;
   if (int rc = s->deferred.ensure(std::max<size_t>(16, (size_t)deferred * max_threads * sizeof(float4)))) return rc;
   P.levels = (float4*)s->levels.p;
@@ -669,13 +696,14 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   uint4* ho_list[4] = {nullptr, nullptr, nullptr, nullptr};
   uint32_t* ho_counters = nullptr;
   size_t touched_bytes = 0;
-  if (literal) {
+  uint32_t counter_words = 0, wf_seg_cap = 0;
+  if (literal || per_level) {
     const uint32_t per = s->bvh_max_depth > 1 ? s->bvh_max_depth - 1 : 1;
     // Rows whose predecessor in the frame is not the end of the tile row above start a chain of their own (halo_find_kernel)
     const bool full_width = tile->x0 == 0 && tile->w == cam.res_x;
     std::vector<uint8_t> chain((size_t)tile->h, 0);
     bool any_chain = false;
-    {
+    if (literal) {
       long long y_prev = -2;
       for (int r = 0; r < tile->h; ++r) {
         const long long y = (long long)tile->y0 + (long long)(r / sh) * sh * ss + (r % sh);
@@ -701,7 +729,17 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     touched_bytes = ((size_t)H.n_units / 32 + 2) * 4;
     if (int rc = s->ho_touched.ensure(touched_bytes)) return rc;
     if (int rc = s->ho_lists.ensure((size_t)4 * H.n_units * sizeof(uint4))) return rc;
-    if (int rc = s->ho_counters.ensure(kHoNumCounters * sizeof(uint32_t))) return rc;
+    // hand-off counters in the first 128-byte line, then one line per (chain level, queue segment) of the per-level launches
+    // ... and the bin counts of every level's ray queue
+    counter_words = 32 + (per_level ? ((uint32_t)cfg->max_depth + 1) * (kWfSegments * kWfCounterStride + kWfHistWords) : 0);
+    if (int rc = s->ho_counters.ensure((size_t)counter_words * sizeof(uint32_t))) return rc;
+    if (per_level) {
+      wf_seg_cap = H.n_units / 4 + 4096;  // a segment takes the rays of every 8th workgroup: twice its fair share
+      if (int rc = s->wf_rays.ensure((size_t)kWfSegments * wf_seg_cap * 2 * sizeof(float4))) return rc;
+      if (int rc = s->wf_keys.ensure((size_t)kWfSegments * wf_seg_cap * sizeof(uint32_t))) return rc;
+      if (int rc = s->wf_sorted.ensure((size_t)H.n_units * 2 * sizeof(float4))) return rc;
+      if (int rc = s->wf_final.ensure((size_t)H.n_units * sizeof(float4))) return rc;
+    }
     H.entries = (uint2*)s->ho_entries.p;
     H.meta = (uint32_t*)s->ho_meta.p;
     H.first = (float4*)s->ho_first.p;
@@ -727,13 +765,11 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     ho_counters = (uint32_t*)s->ho_counters.p;
     H.counters = ho_counters;
   }
-  if (literal || stats) {  // one clear launch at the head of the frame: statistics, hand-off counters, touched bits
+  if (literal || per_level || stats) {  // one clear launch at the head of the frame: statistics, counters, touched bits
     ClearParams C{};
     if (stats) { C.p[0] = (uint32_t*)s->d_stats; C.n[0] = kNumStats * 2; }
-    if (literal) {
-      C.p[1] = ho_counters; C.n[1] = kHoNumCounters;
-      C.p[2] = (uint32_t*)s->ho_touched.p; C.n[2] = (uint32_t)(touched_bytes / 4);
-    }
+    if (literal || per_level) { C.p[1] = ho_counters; C.n[1] = counter_words; }
+    if (literal) { C.p[2] = (uint32_t*)s->ho_touched.p; C.n[2] = (uint32_t)(touched_bytes / 4); }
     if (stats) P3D_HIP(hipEventRecord(s->ev0, st));
     const uint32_t words = std::max(C.n[0], std::max(C.n[1], C.n[2]));
     hipLaunchKernelGGL(clear_kernel, dim3(std::min<uint32_t>(256, (words + 255) / 256)), dim3(256), 0, st, C);
@@ -778,8 +814,48 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       P.rgb = d_rgb ? d_rgb + 3 * off : nullptr;
       P.hit_id = d_hit ? d_hit + off : nullptr;
       P.rgb8 = d_rgb8 ? d_rgb8 + 3 * off : nullptr;
-      hipError_t e;
-      if (literal) {
+      hipError_t e = hipSuccess;
+      if (per_level && pass == 0) {
+        // level 0 over the tiles (+ halo chains), then one launch per chain level over the queue the level above wrote,
+        // then the fold.  The grid of a queue launch is fixed (the queue length is only known on the device): 24 waves
+        // per CU, each taking every (grid / 8)-th chunk of 64 entries of its segment.
+        P.wf_seg_cap = wf_seg_cap;
+        P.wf_final = (float4*)s->wf_final.p;
+        P.level_stride2 = H.n_units;
+        uint32_t* wf_counters = ho_counters + 32;
+        uint32_t* wf_hists = wf_counters + (size_t)((uint32_t)cfg->max_depth + 1) * kWfSegments * kWfCounterStride;
+        const uint32_t queue_blocks = std::min<uint32_t>(kWfSegments * 768, std::max<uint32_t>(kWfSegments, (max_threads / kBlock) / kWfSegments * kWfSegments));
+        P.wf_ray_out = (float4*)s->wf_rays.p; P.wf_ray_in = (float4*)s->wf_rays.p;
+        P.wf_key_out = (uint32_t*)s->wf_keys.p; P.wf_key_in = (const uint32_t*)s->wf_keys.p;
+        P.wf_sorted = (float4*)s->wf_sorted.p;
+        P.wf_cell_origin = F3{s->root_min[0], s->root_min[1], s->root_min[2]};
+        auto scale = [&](int a) { const float w = s->root_max[a] - s->root_min[a]; return w > 0 ? (float)kWfCellsPerAxis / w : 0.0f; };
+        P.wf_cell_scale = F3{scale(0), scale(1), scale(2)};
+        for (int level = 0; level <= cfg->max_depth && e == hipSuccess; ++level) {
+          P.wf_level = (uint32_t)level;
+          P.wf_n_out = wf_counters + (size_t)level * kWfSegments * kWfCounterStride;
+          P.wf_hist = wf_hists + (size_t)level * kWfHistWords;
+          P.wf_total = level ? wf_hists + (size_t)(level - 1) * kWfHistWords + kWfBins : nullptr;
+          const uint32_t g = level == 0 ? blocks : queue_blocks;
+          P.level_stride = g * kBlock;
+          if (want_counts && literal) hipLaunchKernelGGL((wf_level_kernel<true, 1>), dim3(g), dim3(kBlock), lds_bytes, st, P);
+          else if (want_counts) hipLaunchKernelGGL((wf_level_kernel<true, 0>), dim3(g), dim3(kBlock), lds_bytes, st, P);
+          else if (literal) hipLaunchKernelGGL((wf_level_kernel<false, 1>), dim3(g), dim3(kBlock), lds_bytes, st, P);
+          else hipLaunchKernelGGL((wf_level_kernel<false, 0>), dim3(g), dim3(kBlock), lds_bytes, st, P);
+          e = hipGetLastError();
+          if (e == hipSuccess && level < cfg->max_depth) {  // put the child rays in bin order for the next level
+            hipLaunchKernelGGL(wf_scan_kernel, dim3(1), dim3(1024), 0, st, P.wf_hist);
+            P.wf_n_in = P.wf_n_out;
+            hipLaunchKernelGGL(wf_scatter_kernel, dim3(kWfSegments * 128), dim3(256), 0, st, P, (const uint32_t*)(P.wf_hist + kWfBins));
+            e = hipGetLastError();
+          }
+        }
+        if (e == hipSuccess) {
+          hipLaunchKernelGGL(wf_fold_kernel, dim3(((uint32_t)tile->w * (uint32_t)tile->h + 255) / 256), dim3(256), 0, st, P);
+          e = hipGetLastError();
+        }
+        P.level_stride = blocks * kBlock;
+      } else if (literal) {
         if (pass == 1) { H.list_out = ho_list[0]; H.n_out = ho_counters + kHoListA; }
         e = launch_literal(pass == 0 ? 1 : 0, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
       } else {
@@ -857,21 +933,22 @@ int p3d_render_tile(p3d_scene* s, const p3d_config* cfg, const p3d_tile* tile, f
 }
 
 static int trace_common(p3d_scene* s, uint32_t accel, uint32_t n, const float* origin, const float* direction, int32_t* hit_id,
-                        float* hit_point, uint8_t* occluded, bool any) {
+                        float* t_host, float* hit_point, uint8_t* occluded, bool any) {
   if (!s || !origin || !direction || (any ? !occluded : !hit_id)) return fail(P3D_ERR_INVALID, "p3d_trace: null argument");
   if (int rc = check_accel(s, accel)) return rc;
   if (accel == P3D_ACCEL_GRID && s->dev.n_objs == 0) return fail(P3D_ERR_UNSUPPORTED, "grid over an empty scene");
   if (n == 0) return P3D_OK;
   P3D_HIP(hipSetDevice(s->device));
   const size_t in_bytes = (size_t)n * 6 * sizeof(float);
-  const size_t out_bytes = (size_t)n * (sizeof(int32_t) + 3 * sizeof(float) + 1) + 64;
+  const size_t out_bytes = (size_t)n * (sizeof(int32_t) + 4 * sizeof(float) + 1) + 256;
   if (int rc = s->q_in.ensure(in_bytes)) return rc;
   if (int rc = s->q_out.ensure(out_bytes)) return rc;
   float* d_o = (float*)s->q_in.p;
   float* d_d = d_o + (size_t)n * 3;
   int32_t* d_hit = (int32_t*)s->q_out.p;
   float* d_hp = (float*)(d_hit + n);
-  uint8_t* d_occ = (uint8_t*)(d_hp + (size_t)n * 3);
+  float* d_t = d_hp + (size_t)n * 3;
+  uint8_t* d_occ = (uint8_t*)(d_t + n);
   P3D_HIP(hipMemcpy(d_o, origin, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
   P3D_HIP(hipMemcpy(d_d, direction, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
   const uint32_t bound = accel == P3D_ACCEL_BVH ? std::max<uint32_t>(1, s->bvh_max_depth) : 1;
@@ -880,7 +957,7 @@ static int trace_common(p3d_scene* s, uint32_t accel, uint32_t n, const float* o
   if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)(bound - cap) * blocks * kBlock * sizeof(uint2)))) return rc;
   TraceParams P{};
   P.sc = s->dev; P.n = n; P.origin = d_o; P.direction = d_d; P.hit_id = d_hit; P.hit_point = d_hp; P.occluded = d_occ;
-  P.t = nullptr; P.spill = (uint2*)s->spill.p; P.spill_stride = blocks * kBlock; P.stack_cap = (int32_t)cap;
+  P.t = t_host ? d_t : nullptr; P.spill = (uint2*)s->spill.p; P.spill_stride = blocks * kBlock; P.stack_cap = (int32_t)cap;
   const size_t lds = (size_t)cap * kBlock * sizeof(uint2);
 #define P3D_TRACE(A)                                                                                     \
   do {                                                                                                   \
@@ -898,17 +975,60 @@ static int trace_common(p3d_scene* s, uint32_t accel, uint32_t n, const float* o
   } else {
     P3D_HIP(hipMemcpy(hit_id, d_hit, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (hit_point) P3D_HIP(hipMemcpy(hit_point, d_hp, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (t_host) P3D_HIP(hipMemcpy(t_host, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   }
   return P3D_OK;
 }
 
 int p3d_trace_closest(p3d_scene* s, uint32_t accel, uint32_t n, const float* origin, const float* direction, int32_t* hit_id,
                       float* t, float* hit_point) {
-  (void)t;  // BVH / grid report the hit point only (bvh.cpp:271, grid.cpp:110); kept for ABI symmetry
-  return trace_common(s, accel, n, origin, direction, hit_id, hit_point, nullptr, false);
+  return trace_common(s, accel, n, origin, direction, hit_id, t, hit_point, nullptr, false);
 }
 int p3d_trace_any(p3d_scene* s, uint32_t accel, uint32_t n, const float* origin, const float* direction, uint8_t* occluded) {
-  return trace_common(s, accel, n, origin, direction, nullptr, nullptr, occluded, true);
+  return trace_common(s, accel, n, origin, direction, nullptr, nullptr, nullptr, occluded, true);
+}
+
+static int object_query(p3d_scene* s, int what, uint32_t object, uint32_t n, const float* a, float* b, uint8_t* hit, float* t) {
+  if (!s || !a || !b || (what == 0 && (!hit || !t))) return fail(P3D_ERR_INVALID, "p3d object query: null argument");
+  if (what != 2 && object >= s->dev.n_objs) return fail(P3D_ERR_INVALID, "p3d object query: no such object");
+  if (what == 2 && !s->has_sky) return fail(P3D_ERR_INVALID, "p3d_skybox_color: no cubemap was supplied (p3d_scene_set_skybox)");
+  if (n == 0) return P3D_OK;
+  P3D_HIP(hipSetDevice(s->device));
+  const size_t vec = (size_t)n * 3 * sizeof(float);
+  if (int rc = s->q_in.ensure(vec)) return rc;
+  if (int rc = s->q_out.ensure(vec + (size_t)n * (sizeof(float) + 1) + 64)) return rc;
+  float* d_a = (float*)s->q_in.p;
+  float* d_b = (float*)s->q_out.p;
+  float* d_t = d_b + (size_t)n * 3;
+  uint8_t* d_hit = (uint8_t*)(d_t + n);
+  P3D_HIP(hipMemcpy(d_a, a, vec, hipMemcpyHostToDevice));
+  if (what == 0) {
+    P3D_HIP(hipMemcpy(d_b, b, vec, hipMemcpyHostToDevice));
+    P3D_HIP(hipMemcpy(d_t, t, (size_t)n * sizeof(float), hipMemcpyHostToDevice));  // untouched where the test fails
+  }
+  ObjectQueryParams Q{};
+  Q.sc = s->dev; Q.object = object; Q.n = n; Q.a = d_a; Q.b = d_b; Q.hit = d_hit; Q.t = d_t;
+  const uint32_t blocks = (n + kBlock - 1) / kBlock;
+  if (what == 0) hipLaunchKernelGGL((object_query_kernel<0>), dim3(blocks), dim3(kBlock), 0, 0, Q);
+  else if (what == 1) hipLaunchKernelGGL((object_query_kernel<1>), dim3(blocks), dim3(kBlock), 0, 0, Q);
+  else hipLaunchKernelGGL((object_query_kernel<2>), dim3(blocks), dim3(kBlock), 0, 0, Q);
+  P3D_HIP(hipGetLastError());
+  P3D_HIP(hipDeviceSynchronize());
+  P3D_HIP(hipMemcpy(b, d_b, vec, hipMemcpyDeviceToHost));
+  if (what == 0) {
+    P3D_HIP(hipMemcpy(hit, d_hit, n, hipMemcpyDeviceToHost));
+    P3D_HIP(hipMemcpy(t, d_t, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  return P3D_OK;
+}
+int p3d_object_intercepts(p3d_scene* s, uint32_t object, uint32_t n, const float* origin, float* direction, uint8_t* hit, float* t) {
+  return object_query(s, 0, object, n, origin, direction, hit, t);
+}
+int p3d_object_normal(p3d_scene* s, uint32_t object, uint32_t n, const float* point, float* normal) {
+  return object_query(s, 1, object, n, point, normal, nullptr, nullptr);
+}
+int p3d_skybox_color(p3d_scene* s, uint32_t n, const float* direction, float* rgb) {
+  return object_query(s, 2, 0, n, direction, rgb, nullptr, nullptr);
 }
 
 #ifdef P3D_PT_PROFILE

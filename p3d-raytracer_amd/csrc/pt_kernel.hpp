@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
         F3 gc = color;
         if (P.gamma != 1.0f) {
           const double ig = (double)(1 / P.gamma);
-          gc = f3((float)pow((double)color.x, ig), (float)pow((double)color.y, ig), (float)pow((double)color.z, ig));
+          gc = f3((float)pow_spec((double)color.x, ig), (float)pow_spec((double)color.y, ig), (float)pow_spec((double)color.z, ig));
         }
         P.rgb8[3 * k] = u8fromfloat(gc.x); P.rgb8[3 * k + 1] = u8fromfloat(gc.y); P.rgb8[3 * k + 2] = u8fromfloat(gc.z);
       }

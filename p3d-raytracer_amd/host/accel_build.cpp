@@ -1,6 +1,8 @@
 // accel_build.cpp — BVH and uniform-grid construction (host).
 #include "accel_build.hpp"
 
+#include "p3d_error.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <memory>
@@ -26,8 +28,45 @@ inline void put3(float dst[3], const Vector& v) { dst[0] = v.x; dst[1] = v.y; ds
 // Bounding boxes / centroids are cached per object: the values are what the virtual
 // calls of the reference return, computed once.
 // ---------------------------------------------------------------------------
+// bvh.cpp:198-276 / 278-340 as single queries on the device scene
+bool BVH::intersect_bvh(Ray ray, Object** hit_obj, Vector& hit_point) {
+  if (!dev_) { fail(P3D_ERR_NO_DEVICE, "BVH::intersect_bvh: no device scene bound (BVH::bindDevice)"); return false; }
+  const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z}, d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};
+  int32_t id = -1;
+  float hp[3] = {0, 0, 0};
+  if (p3d_trace_closest(dev_, P3D_ACCEL_BVH, 1, o, d, &id, nullptr, hp) != P3D_OK || id < 0) return false;
+  if (hit_obj && (size_t)id < scene_order_.size()) *hit_obj = scene_order_[id];
+  hit_point = Vector(hp[0], hp[1], hp[2]);
+  return true;
+}
+bool BVH::bool_intersect_bvh(Ray ray) {
+  if (!dev_) { fail(P3D_ERR_NO_DEVICE, "BVH::bool_intersect_bvh: no device scene bound (BVH::bindDevice)"); return false; }
+  const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z}, d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};
+  uint8_t occ = 0;
+  return p3d_trace_any(dev_, P3D_ACCEL_BVH, 1, o, d, &occ) == P3D_OK && occ != 0;
+}
+
+// grid.cpp:71-151 / 154-208 as single queries on the device scene
+bool Grid::Traverse(Ray& ray, Object** hitobject, Vector& hitpoint) {
+  if (!dev_) { fail(P3D_ERR_NO_DEVICE, "Grid::Traverse: no device scene bound (Grid::bindDevice)"); return false; }
+  const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z}, d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};
+  int32_t id = -1;
+  float hp[3] = {0, 0, 0};
+  if (p3d_trace_closest(dev_, P3D_ACCEL_GRID, 1, o, d, &id, nullptr, hp) != P3D_OK || id < 0) return false;
+  if (hitobject && (size_t)id < objects_.size()) *hitobject = objects_[id];
+  hitpoint = Vector(hp[0], hp[1], hp[2]);
+  return true;
+}
+bool Grid::Traverse(Ray& ray) {
+  if (!dev_) { fail(P3D_ERR_NO_DEVICE, "Grid::Traverse: no device scene bound (Grid::bindDevice)"); return false; }
+  const float o[3] = {ray.origin.x, ray.origin.y, ray.origin.z}, d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};
+  uint8_t occ = 0;
+  return p3d_trace_any(dev_, P3D_ACCEL_GRID, 1, o, d, &occ) == P3D_OK && occ != 0;
+}
+
 void BVH::build(const std::vector<Object*>& objects) {
   objs_ = objects;
+  scene_order_ = objects;
   const size_t n = objs_.size();
   order_.resize(n);
   nodes_.clear();

@@ -16,10 +16,15 @@
 
 namespace p3d {
 
-// bvh.cpp:28-196 (build only; intersect_bvh / bool_intersect_bvh run on the device)
+// bvh.cpp:28-196: build on the host; intersect_bvh / bool_intersect_bvh (bvh.cpp:198-340) forward ONE query to the
+// device scene (p3d_trace_closest / p3d_trace_any with accel = Bvh).  Every forwarded query starts on an empty
+// traversal stack: the member hit_stack that outlives a query (bvh.cpp:86) exists inside a frame render only.
 class BVH {
  public:
   void build(const std::vector<Object*>& objects);
+  void bindDevice(::p3d_scene* dev) { dev_ = dev; }
+  bool intersect_bvh(Ray ray, Object** hit_obj, Vector& hit_point);
+  bool bool_intersect_bvh(Ray ray);
   const std::vector<p3d_bvh_node>& flatNodes() const { return nodes_; }
   const std::vector<uint32_t>& primOrder() const { return order_; }  // permuted objs (bvh.cpp:84)
   uint32_t maxDepth() const { return max_depth_; }
@@ -47,11 +52,18 @@ class BVH {
   std::vector<SortKey> keys_;
   std::vector<p3d_bvh_node> nodes_;
   uint32_t max_depth_ = 0;
+  std::vector<Object*> scene_order_;  // the objects as passed to build(): hit ID -> Object*
+  ::p3d_scene* dev_ = nullptr;
 };
 
-// grid.h:13-43 / grid.cpp:3-68, 211-259 (build only)
+// grid.h:13-43 / grid.cpp:3-68, 211-259: build on the host; Traverse x2 (grid.cpp:71-208) forward ONE query to the
+// device scene (p3d_trace_closest / p3d_trace_any with accel = UGrid; the any-hit form includes the object loop that
+// follows the grid query in the reference's shadow code, main.cpp:197-217).
 class Grid {
  public:
+  void bindDevice(::p3d_scene* dev) { dev_ = dev; }
+  bool Traverse(Ray& ray, Object** hitobject, Vector& hitpoint);
+  bool Traverse(Ray& ray);
   int getNumObjects() const { return static_cast<int>(objects_.size()); }
   void addObject(Object* o) { objects_.push_back(o); }
   Object* getObject(unsigned i) const { return objects_.at(i); }
@@ -67,6 +79,17 @@ class Grid {
   int nx = 0, ny = 0, nz = 0;
   float m = 2.0f;  // grid.h:33
   AABB bbox;
+  ::p3d_scene* dev_ = nullptr;
 };
 
+// C++ callers that hold a p3d_host_scene (include/p3d.h) reach the classes inside it through this
+struct HostClasses {
+  Scene* scene;
+  BVH* bvh;    // null until p3d_host_scene_desc(build_bvh = 1)
+  Grid* grid;  // null until p3d_host_scene_desc(build_grid = 1)
+};
+}  // namespace p3d
+struct p3d_host_scene;
+namespace p3d {
+HostClasses host_classes(::p3d_host_scene* hs);
 }  // namespace p3d

@@ -173,4 +173,15 @@ int p3d_host_scene_desc(p3d_host_scene* hs, int build_bvh, int build_grid, const
   return P3D_OK;
 }
 
+int p3d_host_scene_bind_device(p3d_host_scene* hs, p3d_scene* scene) {
+  if (!hs) return p3d::fail(P3D_ERR_INVALID, "p3d_host_scene_bind_device: null argument");
+  if (hs->bvh) hs->bvh->bindDevice(scene);
+  if (hs->grid) hs->grid->bindDevice(scene);
+  return hs->scene.bindDevice(scene) ? P3D_OK : P3D_ERR_NO_DEVICE;
+}
+
 }  // extern "C"
+
+namespace p3d {
+HostClasses host_classes(::p3d_host_scene* hs) { return HostClasses{&hs->scene, hs->bvh.get(), hs->grid.get()}; }
+}  // namespace p3d

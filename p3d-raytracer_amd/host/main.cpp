@@ -5,7 +5,10 @@
 //
 //   p3d_render [scene.p3f] [--whitted|--pathtrace] [--accel none|grid|bvh] [--depth N]
 //              [--spp N(sqrt)] [--aa 0|1] [--dof 0|1] [--soft 0|1] [--tent] [--gamma G]
-//              [--res W H] [--seed S] [--legacy-f11] [--out image.ppm] [--device D]
+//              [--res W H] [--seed S] [--legacy-f11] [--device D]
+//              [--out image.png|image.ppm]   default RT_Output.png, as saveImgFile writes it (main.cpp:674-689,851);
+//                               PNG through zlib (8-bit RGB, no DevIL), a name ending in .ppm gives a binary PPM
+//              [--stack literal|per_pixel]   p3d_config.stack_mode (default literal: the reference's one hit_stack)
 //              [--device-bvh]   build a linear BVH on the GPU instead of the reference's tree on the host
 //                               (p3d_scene_create_device_bvh: same closest hits, shadow feelers may differ)
 //              [--skybox DIR]   DIR/{right,left,top,bottom,front,back}.ppm (binary P6; convert the
@@ -18,6 +21,8 @@
 #include <iostream>
 #include <string>
 #include <vector>
+
+#include <zlib.h>
 
 #include "p3d.h"
 
@@ -35,6 +40,42 @@ bool save_ppm(const std::string& path, const std::vector<uint8_t>& rgb8, int w, 
   if (!f) return false;
   f << "P6\n" << w << " " << h << "\n255\n";
   for (int y = h - 1; y >= 0; --y) f.write(reinterpret_cast<const char*>(&rgb8[(size_t)y * w * 3]), (std::streamsize)w * 3);
+  return (bool)f;
+}
+
+// saveImgFile (main.cpp:674-689) without DevIL: 8-bit RGB PNG, one IDAT chunk, filter type 0 on every scanline.
+bool save_png(const std::string& path, const std::vector<uint8_t>& rgb8, int w, int h) {
+  std::vector<uint8_t> raw((size_t)h * (1 + (size_t)w * 3));
+  for (int y = 0; y < h; ++y) {  // file rows are top-down, img_Data is bottom-up
+    uint8_t* row = &raw[(size_t)y * (1 + (size_t)w * 3)];
+    row[0] = 0;
+    std::memcpy(row + 1, &rgb8[(size_t)(h - 1 - y) * w * 3], (size_t)w * 3);
+  }
+  uLongf zlen = compressBound((uLong)raw.size());
+  std::vector<uint8_t> z(zlen);
+  if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+  std::ofstream f(path, std::ios::binary);
+  if (!f) return false;
+  auto be32 = [](uint32_t v, uint8_t* p) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; };
+  auto chunk = [&](const char type[4], const uint8_t* data, uint32_t n) {
+    uint8_t len[4], crcb[4];
+    be32(n, len);
+    f.write(reinterpret_cast<const char*>(len), 4);
+    f.write(type, 4);
+    if (n) f.write(reinterpret_cast<const char*>(data), n);
+    uLong crc = crc32(0L, reinterpret_cast<const Bytef*>(type), 4);
+    if (n) crc = crc32(crc, data, n);
+    be32((uint32_t)crc, crcb);
+    f.write(reinterpret_cast<const char*>(crcb), 4);
+  };
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  f.write(reinterpret_cast<const char*>(sig), 8);
+  uint8_t ihdr[13];
+  be32((uint32_t)w, ihdr); be32((uint32_t)h, ihdr + 4);
+  ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;  // 8 bits, colour type 2 (RGB)
+  chunk("IHDR", ihdr, 13);
+  chunk("IDAT", z.data(), (uint32_t)zlen);
+  chunk("IEND", nullptr, 0);
   return (bool)f;
 }
 
@@ -61,7 +102,7 @@ bool load_ppm_face(const std::string& path, std::vector<uint8_t>& bytes, uint32_
 int main(int argc, char** argv) {
   p3d_config cfg;
   p3d_config_default(&cfg);
-  std::string scene_path, skybox_dir, out = "RT_Output.ppm";  // main.cpp:851 writes RT_Output.png
+  std::string scene_path, skybox_dir, out = "RT_Output.png";  // main.cpp:851
   int res_w = 0, res_h = 0, device = 0;
   bool device_bvh = false;
   uint32_t load_flags = 0;
@@ -88,6 +129,7 @@ int main(int argc, char** argv) {
     else if (a == "--legacy-f11") load_flags |= P3D_LOAD_LEGACY_F11;
     else if (a == "--out") out = next("--out");
     else if (a == "--skybox") skybox_dir = next("--skybox");
+    else if (a == "--stack") cfg.stack_mode = std::string(next("--stack")) == "per_pixel" ? P3D_STACK_PER_PIXEL : P3D_STACK_LITERAL;
     else if (a == "--device") device = std::atoi(next("--device"));
     else if (a == "--device-bvh") device_bvh = true;
     else if (a[0] != '-') scene_path = a;
@@ -155,7 +197,8 @@ int main(int argc, char** argv) {
   std::printf("accel build + upload %.3f s; kernel %.3f ms; %llu rays; %.1f Mrays/s (kernel)\n",
               std::chrono::duration<double>(t_build1 - t_build0).count(), st.kernel_ms, (unsigned long long)rays,
               st.kernel_ms > 0 ? rays / (st.kernel_ms * 1e3) : 0.0);
-  if (!save_ppm(out, img, W, H)) {
+  const bool ppm = out.size() > 4 && out.compare(out.size() - 4, 4, ".ppm") == 0;
+  if (!(ppm ? save_ppm(out, img, W, H) : save_png(out, img, W, H))) {
     std::printf("Error saving Image file\n");
     return 1;
   }

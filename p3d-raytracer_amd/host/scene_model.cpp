@@ -1,6 +1,9 @@
 // scene_model.cpp — shape constructors, camera frame and the .p3f loader of the host side.
 #include "scene_model.hpp"
 
+#include "p3d.h"
+#include "p3d_error.hpp"
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -8,6 +11,8 @@
 #include <fstream>
 #include <functional>
 #include <map>
+#include <string>
+#include <vector>
 
 namespace p3d {
 
@@ -77,7 +82,110 @@ Camera::Camera(const Vector& from, const Vector& At, const Vector& Up, float ang
   aperture = Aperture_ratio * (w / res_x);  // lens aperture = ratio * pixel size
 }
 
+// camera.h:65-82
+Ray Camera::PrimaryRay(const Vector& pixel_sample) {
+  Vector ps;
+  ps.x = w * (pixel_sample.x / res_x - 0.5f);
+  ps.y = h * (pixel_sample.y / res_y - 0.5f);
+  ps.z = -plane_dist;
+  const Vector vX = u * ps.x, vY = v * ps.y, vZ = n * ps.z;
+  Vector ray_dir = vX + vY + vZ;
+  ray_dir.normalize();
+  return Ray(eye, ray_dir);
+}
+// camera.h:84-115
+Ray Camera::PrimaryRay(const Vector& lens_sample, const Vector& pixel_sample) {
+  Vector ps;
+  ps.x = w * (pixel_sample.x / res_x - 0.5f);
+  ps.y = h * (pixel_sample.y / res_y - 0.5f);
+  ps.z = -plane_dist;
+  Vector ls;
+  ls.x = lens_sample.x * aperture;
+  ls.y = lens_sample.y * aperture;
+  ls.z = 0;
+  Vector p;
+  p.x = ps.x * focal_ratio;
+  p.y = ps.y * focal_ratio;
+  const Vector vX = u * (p.x - ls.x), vY = v * (p.y - ls.y), vZ = n * -(focal_ratio * plane_dist);
+  Vector ray_dir = vX + vY + vZ;
+  ray_dir.normalize();
+  const Vector eye_offset = eye + (u * ls.x) + (v * ls.y);
+  return Ray(eye_offset, ray_dir);
+}
+
+// ---- Object: the two virtuals of scene.h:88-89, answered by the device ----------
+bool Object::intercepts(Ray& r, float& t) {
+  if (!dev_) { fail(P3D_ERR_NO_DEVICE, "Object::intercepts: the scene is not bound to a device scene (Scene::bindDevice)"); return false; }
+  const float o[3] = {r.origin.x, r.origin.y, r.origin.z};
+  float d[3] = {r.direction.x, r.direction.y, r.direction.z};
+  uint8_t hit = 0;
+  float tt = t;
+  if (p3d_object_intercepts(dev_, index_, 1, o, d, &hit, &tt) != P3D_OK) return false;
+  r.direction = Vector(d[0], d[1], d[2]);  // Sphere::intercepts normalises the caller's ray (scene.cpp:156)
+  if (hit) t = tt;
+  return hit != 0;
+}
+Vector Object::getNormal(Vector point) {
+  if (!dev_) { fail(P3D_ERR_NO_DEVICE, "Object::getNormal: the scene is not bound to a device scene (Scene::bindDevice)"); return Vector(); }
+  const float p[3] = {point.x, point.y, point.z};
+  float nrm[3] = {0, 0, 0};
+  if (p3d_object_normal(dev_, index_, 1, p, nrm) != P3D_OK) return Vector();
+  return Vector(nrm[0], nrm[1], nrm[2]);
+}
+
 // ---- Scene --------------------------------------------------------------------
+bool Scene::bindDevice(::p3d_scene* dev) {
+  dev_ = dev;
+  for (size_t i = 0; i < objects.size(); ++i) objects[i]->bind(dev, static_cast<uint32_t>(i));
+  if (dev && skybox_loaded) {
+    p3d_skybox_desc sky{};
+    for (int f = 0; f < 6; ++f) {
+      sky.face[f].img = skybox_img[f].img.data();
+      sky.face[f].res_x = skybox_img[f].resX; sky.face[f].res_y = skybox_img[f].resY; sky.face[f].bpp = skybox_img[f].BPP;
+    }
+    return p3d_scene_set_skybox(dev, &sky) == P3D_OK;
+  }
+  return true;
+}
+
+// scene.cpp:329-377 with binary PPM faces instead of DevIL-decoded JPEGs (see the header)
+bool Scene::LoadSkybox(const char* sky_dir) {
+  static const char* maps[6] = {"/right", "/left", "/top", "/bottom", "/front", "/back"};  // scene.cpp:333
+  for (int f = 0; f < 6; ++f) {
+    const std::string path = std::string(sky_dir) + maps[f] + ".ppm";
+    std::ifstream file(path, std::ios::binary);
+    std::string magic;
+    uint32_t w = 0, h = 0;
+    int maxv = 0;
+    if (file) file >> magic >> w >> h >> maxv;
+    if (!file || magic != "P6" || maxv != 255 || w == 0 || h == 0) {
+      fail(P3D_ERR_IO, "Scene::LoadSkybox: cannot read " + path + " (binary PPM; scenes/skybox_to_ppm.py converts the JPEG folder)");
+      return false;
+    }
+    file.get();
+    std::vector<uint8_t> top_down((size_t)w * h * 3);
+    file.read(reinterpret_cast<char*>(top_down.data()), (std::streamsize)top_down.size());
+    if (!file) { fail(P3D_ERR_IO, "Scene::LoadSkybox: short file " + path); return false; }
+    Face& F = skybox_img[f];
+    F.resX = w; F.resY = h; F.BPP = 3;
+    F.img.resize(top_down.size());
+    for (uint32_t y = 0; y < h; ++y)  // IL_ORIGIN_LOWER_LEFT (scene.cpp:344-345): bottom row first
+      std::memcpy(&F.img[(size_t)y * w * 3], &top_down[(size_t)(h - 1 - y) * w * 3], (size_t)w * 3);
+    std::printf("Skybox face %d: Image sucessfully loaded.\n", f);  // scene.cpp:352
+  }
+  skybox_loaded = true;
+  skyboxDir = sky_dir;
+  return dev_ ? bindDevice(dev_) : true;
+}
+
+Color Scene::GetSkyboxColor(Ray& r) {
+  if (!dev_) { fail(P3D_ERR_NO_DEVICE, "Scene::GetSkyboxColor: the scene is not bound to a device scene (Scene::bindDevice)"); return Color(); }
+  const float d[3] = {r.direction.x, r.direction.y, r.direction.z};  // the RAW direction (scene.cpp:381)
+  float rgb[3] = {0, 0, 0};
+  if (p3d_skybox_color(dev_, 1, d, rgb) != P3D_OK) return Color();
+  return Color(rgb[0], rgb[1], rgb[2]);
+}
+
 int Scene::materialIndex(const Material* m) const {
   for (size_t i = 0; i < materials.size(); ++i)
     if (materials[i].get() == m) return static_cast<int>(i);

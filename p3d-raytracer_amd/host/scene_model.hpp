@@ -2,11 +2,16 @@
 //
 // Keeps the reference's API surface (class and method names of Raytracing/scene.h:34-225,
 // camera.h:15-116, vector.h, color.h, boundingBox.h) so that code written against the
-// reference's Scene / Camera / Object / Material / Light getters keeps compiling, but the
-// classes here only DESCRIBE the scene: all ray queries (Object::intercepts, getNormal,
-// BVH/Grid traversal, rayTracing, Radiance) are served by the HIP kernels behind
-// include/p3d.h.  The host builds the acceleration structures (as the reference does,
-// main.cpp:701-720) and flattens everything into a p3d_scene_desc.
+// reference's Scene / Camera / Object / Material / Light getters keeps compiling.  The classes
+// DESCRIBE the scene; every ray query — Object::intercepts / getNormal, BVH::intersect_bvh /
+// bool_intersect_bvh, Grid::Traverse x2, Scene::GetSkyboxColor, and of course rayTracing /
+// Radiance — is answered by the HIP kernels behind include/p3d.h: the methods of those names
+// below forward ONE query to the device scene the host scene was bound to (Scene::bindDevice)
+// and fail (false / zero vector, p3d_last_error set) when there is none.  There is no host
+// implementation of any intersection test in this library.  Only Camera::PrimaryRay (camera.h:65-115,
+// a dozen float operations, as header-only in the reference) computes on the host.  The host
+// builds the acceleration structures (as the reference does, main.cpp:701-720) and flattens
+// everything into a p3d_scene_desc.
 #pragma once
 
 #include <cfloat>
@@ -15,6 +20,8 @@
 #include <memory>
 #include <string>
 #include <vector>
+
+struct p3d_scene;  // include/p3d.h: the device-resident scene
 
 namespace p3d {
 
@@ -40,6 +47,17 @@ struct Vector {
   Vector operator%(const Vector& o) const {                                       // cross product
     return {y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x};
   }
+};
+
+// ---- ray.h ------------------------------------------------------------------
+class Ray {
+ public:
+  Ray(const Vector& o, const Vector& dir, int ix = 0, int jx = 0) : origin(o), direction(dir), i(ix), j(jx) {}
+  Vector origin;
+  Vector direction;
+  int i, j;
+  uint64_t id = 0;
+  Vector getDirection() { return direction.normalize(); }  // ray.h:16-18: normalises IN PLACE, every call
 };
 
 // ---- color.h ----------------------------------------------------------------
@@ -128,9 +146,16 @@ class Object {
   virtual Vector getCentroid() const = 0;
   // nine geometry floats + shading normal in the layout of p3d_prim (include/p3d.h)
   virtual void pack(float v[9], float n[3]) const = 0;
+  // scene.h:88-89.  One query on the device (p3d_object_intercepts / p3d_object_normal); the sphere test leaves
+  // r.direction normalised, as the reference's does (scene.cpp:156).
+  bool intercepts(Ray& r, float& t);
+  Vector getNormal(Vector point);
+  void bind(::p3d_scene* dev, uint32_t index) { dev_ = dev; index_ = index; }
 
  protected:
   Material* m_Material = nullptr;
+  ::p3d_scene* dev_ = nullptr;  // set by Scene::bindDevice
+  uint32_t index_ = 0;          // position in Scene::objects = hit ID
 };
 
 class Sphere final : public Object {
@@ -198,6 +223,8 @@ class Camera {
   float GetPlaneDist() const { return plane_dist; }
   float GetFar() const { return vfar; }
   float GetAperture() const { return aperture; }
+  Ray PrimaryRay(const Vector& pixel_sample);                             // camera.h:65-82
+  Ray PrimaryRay(const Vector& lens_sample, const Vector& pixel_sample);  // camera.h:84-115 (thin lens)
   // raw state for the device descriptor
   Vector eye, at, up, u, v, n;
   float fovy, vnear, vfar, plane_dist, focal_ratio, aperture, w, h, aperture_ratio;
@@ -214,9 +241,18 @@ class Scene {
   bool GetSkyBoxFlg() const { return SkyBoxFlg; }
   void SetSkyBoxFlg(bool f) { SkyBoxFlg = f; }
   const std::string& GetSkyboxDir() const { return skyboxDir; }
+  // scene.cpp:329-377: the six faces <dir>/{right,left,top,bottom,front,back}.  The reference decodes JPEGs through
+  // DevIL; this library has no image decoder: the faces are read as binary PPMs (scenes/skybox_to_ppm.py converts a
+  // folder once) and kept bottom row first (IL_ORIGIN_LOWER_LEFT).  Uploaded to the bound device scene, now or at bindDevice.
+  bool LoadSkybox(const char* sky_dir);
+  Color GetSkyboxColor(Ray& r);  // scene.cpp:379-457, one lookup on the device (p3d_skybox_color)
+  // The device scene that answers the ray queries of this scene's objects (p3d_scene_create of this scene's
+  // descriptor).  Not owned.  nullptr unbinds.
+  bool bindDevice(::p3d_scene* dev);
+  ::p3d_scene* device() const { return dev_; }
 
   int getNumObjects() const { return static_cast<int>(objects.size()); }
-  void addObject(Object* o) { objects.emplace_back(o); }
+  void addObject(Object* o) { o->bind(dev_, static_cast<uint32_t>(objects.size())); objects.emplace_back(o); }
   Object* getObject(unsigned i) const { return i < objects.size() ? objects[i].get() : nullptr; }
   int getNumLights() const { return static_cast<int>(lights.size()); }
   void addLight(Light* l) { lights.emplace_back(l); }
@@ -247,6 +283,9 @@ class Scene {
   Color bgColor;
   bool SkyBoxFlg = false;
   std::string skyboxDir;
+  ::p3d_scene* dev_ = nullptr;
+  struct Face { std::vector<uint8_t> img; uint32_t resX = 0, resY = 0, BPP = 3; } skybox_img[6];  // scene.h:218-223
+  bool skybox_loaded = false;
 };
 
 }  // namespace p3d

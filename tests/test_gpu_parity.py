@@ -211,11 +211,12 @@ def test_batched_trace_queries(accel, tri5k_path):
         d[:64, 0] = 0.0          # axis-parallel: 1/0 = inf in the slab test
         d[64:128, 1:] = 0.0
         d[128:1024] *= rng.uniform(0.2, 5, (896, 1)).astype(np.float32)   # unnormalised (Q8)
-        hit, hp = dev.trace_closest(accel, o, d)
-        o_hit, _, o_hp = sc.trace_closest(accel, o, d)
+        hit, hp, t = dev.trace_closest(accel, o, d, want_t=True)
+        o_hit, o_t, o_hp = sc.trace_closest(accel, o, d)
         assert (hit == o_hit).all()
         m = hit >= 0
         assert (hp[m].view(np.uint32) == o_hp[m].view(np.uint32)).all()
+        assert (t.view(np.uint32) == o_t.view(np.uint32)).all()  # tmin / min_t of the traversal, FLT_MAX on a miss
         occ = dev.trace_any(accel, o, d)
         assert (occ == sc.trace_any(accel, o, d)).all()
 
@@ -312,7 +313,8 @@ def test_device_built_bvh_finds_the_same_closest_hits(scene, legacy, tri5k_path)
     #                                                units: the hit point is d * t with d re-normalised on the way, Q8)
     hit_e, p_e = exact.trace_closest(p3d.ACCEL_BVH, o, d)
     hit_b, p_b = built.trace_closest(p3d.ACCEL_BVH, o, d)
-    hit_n, p_n = built.trace_closest(p3d.ACCEL_NONE, o, d)
+    sc = ob.Scene(path, legacy_f11=legacy)
+    hit_n, _, p_n = sc.trace_closest(0, o, d)  # the ORACLE's object loop (main.cpp:116-124): a tree-independent answer
     # The three back ends agree except on grazing rays: every sphere test re-normalises the traversal's copy of
     # the ray (Q8), so the direction a later test sees depends on the tests before it — the reference's own BVH
     # and its own brute-force loop disagree on the same handful of rays (4 of 200 000 on balls_high).
@@ -362,6 +364,53 @@ def test_antialiased_whitted_over_a_scene_traversed_from_l2(kw, tri5k_path):
         assert (a.view(np.uint32) == full[6:35, 10:47].view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("scene,legacy,res,depth", [("tri5k", False, (192, 160), 6), ("balls_high.p3f", True, (160, 160), 4)])
+def test_chain_per_level_launches_write_the_same_bits(scene, legacy, res, depth, tri5k_path):
+    """p3d_config.chain_launch = P3D_CHAIN_PER_LEVEL (one launch per chain level, child rays compacted into a queue
+    and binned by origin cell + direction octant between levels): same queries in the same per-pixel order as the
+    megakernel, so the same bits and the same counters, under both stack modes, also for a striped tile (the halo
+    chains ride on the level-0 launch); and the literal frame equals the oracle's serial order."""
+    dev, sc = _pair(tri5k_path if scene == "tri5k" else scene_path(scene), res=res, legacy=legacy, grid=False)
+    for mode in (p3d.STACK_LITERAL, p3d.STACK_PER_PIXEL):
+        mega = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=depth, stack_mode=mode, chain_launch=p3d.CHAIN_MEGAKERNEL, collect_stats=1)
+        level = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=depth, stack_mode=mode, chain_launch=p3d.CHAIN_PER_LEVEL, collect_stats=1)
+        a_rgb, a_hit, a_st = dev.render(mega)
+        b_rgb, b_hit, b_st = dev.render(level)
+        assert (a_rgb.view(np.uint32) == b_rgb.view(np.uint32)).all() and (a_hit == b_hit).all()
+        for k in COUNTERS + ("max_stack", "handoff_checked", "handoff_redone"):
+            assert getattr(a_st, k) == getattr(b_st, k), k
+        t = p3d.stripe_tile(res, 1, 2, 8)
+        rows = p3d.stripe_rows(res, 1, 2, 8)
+        s_rgb, s_hit, _ = dev.render(level, tile=t)
+        assert (s_rgb.view(np.uint32) == a_rgb[rows].view(np.uint32)).all() and (s_hit == a_hit[rows]).all()
+        if mode == p3d.STACK_LITERAL:
+            o_rgb, o_hit, _ = sc.render(oracle_cfg_like(level))
+            assert_bit_identical((b_rgb, b_hit), (o_rgb, o_hit), "per-level launches, literal hit_stack")
+    with pytest.raises(p3d.P3DError) as e:  # not for a scene that is staged in LDS
+        small, _ = _pair(scene_path("balls_low.p3f"), res=(64, 64), grid=False)
+        small.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=2, chain_launch=p3d.CHAIN_PER_LEVEL))
+    assert e.value.code == -3
+
+
+def test_sample_loop_backstop_is_an_error_not_a_darker_pixel():
+    """The four-lanes-per-pixel kernels hand samples out by ticket inside a wave-uniform loop with a trip bound as
+    backstop.  A pixel that ran into the bound would be written with samples missing: the kernel raises a flag and
+    the call fails with P3D_ERR_CAPACITY (forced here through the debug trip bound)."""
+    dev, _ = _pair(scene_path("path_balls.p3f"), res=(64, 64), grid=False)
+    cfg = p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=4, max_depth=12, seed=3)
+    good, _, _ = dev.render(cfg)
+    L = p3d.lib()
+    try:
+        L.p3d_debug_set_trip_bound(5)
+        with pytest.raises(p3d.P3DError) as e:
+            dev.render(cfg)
+        assert e.value.code == -4 and "trip bound" in str(e.value)
+    finally:
+        L.p3d_debug_set_trip_bound(0)
+    again, _, _ = dev.render(cfg)  # the flag was cleared with the error; the next call is clean
+    assert (again.view(np.uint32) == good.view(np.uint32)).all()
+
+
 @pytest.mark.parametrize("n_objs", [0, 1, 2, 3])
 def test_device_built_bvh_tiny_scenes(n_objs, tmp_path):
     """Degenerate sizes of the GPU builder: no object (no tree), one (the root is a leaf), two and three."""
@@ -381,12 +430,12 @@ def test_device_built_bvh_tiny_scenes(n_objs, tmp_path):
 
 
 def test_rgb8_and_gamma():
-    dev, sc = _pair(scene_path("balls_low.p3f"), res=(96, 96), grid=False)
+    dev, sc = _pair(scene_path("balls_low.p3f"), res=(256, 256), grid=False)
     for gamma in (1.0, 2.2):
         cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=2, gamma=gamma)
         rgb, hit, rgb8, _ = dev.render(cfg, want_rgb8=True)
         _, _, o8, _ = sc.render(oracle_cfg_like(cfg), want_rgb8=True)
-        assert np.abs(rgb8.astype(int) - o8.astype(int)).max() <= (0 if gamma == 1.0 else 1)
+        assert (rgb8 == o8).all()  # bytes are exact, also after pow(c, 1/GAMMA) (main.cpp:814-815; pow_spec on the device)
 
 
 def test_errors_are_reported_not_swallowed():
@@ -479,6 +528,15 @@ def test_p3d_render_cli_writes_the_reference_image(tmp_path):
     sc.set_resolution(160, 120)
     _, _, o8, _ = sc.render(ob.whitted_config(2, 3, stack_mode=1, trace_zero_weight=1), want_rgb8=True)  # the reference's order
     assert (img == o8).all()
+    # and as the PNG that saveImgFile writes (main.cpp:674-689), decoded by an independent reader
+    from PIL import Image
+    png = str(tmp_path / "RT_Output.png")
+    r = subprocess.run([exe, scene_path("balls_low.p3f"), "--whitted", "--accel", "bvh", "--depth", "3", "--aa", "0",
+                        "--res", "160", "120", "--out", png], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    im = Image.open(png)
+    assert im.size == (160, 120) and im.mode == "RGB"
+    assert (np.asarray(im)[::-1] == o8).all()
 
 
 @pytest.mark.parametrize("accel", [p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH])
@@ -554,6 +612,98 @@ def test_skybox_miss_shading(scene, integrator, accel):
     assert np.abs(plain - rgb).max() > 0.05
 
 
+def test_shipped_cubemap_skybox():
+    """SKYBOX true with the reference's own cubemap (Raytracing/skybox/*.jpg, kept as data under
+    tests/golden/skybox/): Scene::LoadSkybox's six faces decoded by PIL on both sides (DevIL in the reference; the
+    decoder and the SHA-256 of the decoded bytes are recorded in decoded.json), Scene::GetSkyboxColor
+    (scene.cpp:379-457) on every miss — primary rays that leave the scene and the sky mirrored in the spheres."""
+    import hashlib
+    import json
+    import PIL
+    from conftest import GOLDEN
+    sky_dir = os.path.join(GOLDEN, "skybox")
+    faces = p3d.load_skybox_dir(sky_dir)
+    rec = json.load(open(os.path.join(sky_dir, "decoded.json")))
+    if PIL.__version__ == rec["PIL"]:  # same decoder build: same texels as when the fixture was recorded
+        for name, f in zip(p3d.SKYBOX_FACE_FILES, faces):
+            assert hashlib.sha256(np.ascontiguousarray(f[::-1]).tobytes()).hexdigest() == rec["faces"][name]["decoded_rgb_sha256"], name
+    dev, sc = _pair(scene_path("balls_low.p3f"), res=(256, 256), grid=False)
+    dev.set_skybox(faces)
+    sc.set_skybox(faces)
+    rgb, hit, _ = check_whitted(dev, sc, p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=3, skybox=1))
+    plain, _, _ = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=3, skybox=0))
+    assert (np.abs(plain - rgb).max(-1) > 0.02).sum() > 500  # the sky shows in the mirror spheres (the floor fills the view)
+    empty, esc = _pair(scene_path("balls_medium.p3f"), res=(128, 128), grid=False)  # shipped parser: 0 objects, every pixel is sky
+    empty.set_skybox(faces)
+    esc.set_skybox(faces)
+    e_rgb, e_hit, _ = check_whitted(empty, esc, p3d.whitted_config(accel=p3d.ACCEL_NONE, max_depth=1, skybox=1))
+    assert (e_hit == -1).all() and len(np.unique(e_rgb.reshape(-1, 3), axis=0)) > 500  # the sky is a picture
+    d = np.random.default_rng(2).standard_normal((4096, 3)).astype(np.float32)
+    d[:16] = np.eye(3, dtype=np.float32)[np.arange(16) % 3] * np.where(np.arange(16) % 2, -1, 1)[:, None]  # exact axes
+    got = dev.skybox_color(d)
+    want = np.stack([sc.skybox_color(v) for v in d])
+    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+
+
+def test_host_class_query_methods_forward_to_the_device(tmp_path):
+    """The reference-named query methods of the host classes (SURVEY.md 8(b)): Camera::PrimaryRay x2 (host arithmetic,
+    camera.h:65-115), Object::intercepts / getNormal, BVH::intersect_bvh / bool_intersect_bvh, Grid::Traverse x2,
+    Scene::LoadSkybox + GetSkyboxColor (each ONE query on the bound device scene).  tests/host_api_check.cpp calls
+    them as code written against the reference would; every record is compared with the oracle, bit for bit."""
+    import subprocess
+    from PIL import Image
+    from conftest import GOLDEN, ROOT
+    exe = str(tmp_path / "host_api_check")
+    pkg = os.path.join(ROOT, "p3d-raytracer_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(pkg, "host"),
+                           os.path.join(ROOT, "tests", "host_api_check.cpp"), "-L" + pkg, "-lp3d", "-Wl,-rpath," + pkg, "-o", exe])
+    ppm_dir = tmp_path / "sky"
+    ppm_dir.mkdir()
+    small = []
+    for name in p3d.SKYBOX_FACE_FILES:  # small faces: the lookup is what is under test here
+        img = Image.open(os.path.join(GOLDEN, "skybox", name + ".jpg")).convert("RGB").resize((96, 64))
+        img.save(str(ppm_dir / (name + ".ppm")))
+        small.append(np.ascontiguousarray(np.asarray(img)[::-1]))
+    scene = scene_path("balls_low.p3f")
+    r = subprocess.run([exe, scene, str(ppm_dir)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    sc = ob.Scene(scene)
+    sc.set_skybox(small)
+    f32 = lambda xs: np.array([float.fromhex(x) for x in xs], np.float32)
+    same = lambda a, b: (np.asarray(a, np.float32).view(np.uint32) == np.asarray(b, np.float32).view(np.uint32)).all()
+    seen = {}
+    for line in r.stdout.splitlines():
+        tag, *v = line.split()
+        if tag == "Skybox":  # "Skybox face N: Image sucessfully loaded." (scene.cpp:352)
+            continue
+        seen[tag] = seen.get(tag, 0) + 1
+        if tag == "UNBOUND":
+            assert v == ["0", "0", "0"]  # no device scene bound: the queries fail, nothing is computed on the host
+        elif tag == "PRIMARY":
+            x = f32(v)
+            o, d = sc.primary_ray(x[0], x[1])
+            lo, ld = sc.primary_ray_lens(x[2], x[3], x[0], x[1])
+            assert same(x[4:7], o) and same(x[7:10], d) and same(x[10:13], lo) and same(x[13:16], ld)
+        elif tag == "OBJ":
+            obj, x, hit, rest = int(v[0]), f32(v[1:7]), int(v[7]), f32(v[8:12])
+            h, t, d_after = sc.object_intercepts(obj, x[0:3], x[3:6])
+            assert hit == int(h) and same(rest[1:4], d_after)
+            assert same(rest[0], np.float32(t)) if h else rest[0] == -1.0
+        elif tag == "NORMAL":
+            obj, x = int(v[0]), f32(v[1:7])
+            assert same(x[3:6], sc.object_normal(obj, x[0:3]))
+        elif tag in ("BVH", "GRID"):
+            accel = 2 if tag == "BVH" else 1
+            x, hid, hp, occ = f32(v[0:6]), int(v[6]), f32(v[7:10]), int(v[10])
+            o_hit, _, o_hp = sc.trace_closest(accel, x[None, 0:3], x[None, 3:6])
+            assert hid == int(o_hit[0]) and (hid < 0 or same(hp, o_hp[0]))
+            assert occ == int(sc.trace_any(accel, x[None, 0:3], x[None, 3:6])[0])
+        elif tag == "SKY":
+            x = f32(v)
+            assert same(x[3:6], sc.skybox_color(x[0:3]))
+    assert seen == {"UNBOUND": 1, "PRIMARY": 8, "OBJ": 64, "NORMAL": 64, "BVH": 64, "GRID": 64, "SKY": 64}, seen
+
+
 def test_skybox_requested_without_cubemap_is_an_error():
     dev, _ = _pair(scene_path("balls_low.p3f"), res=(32, 32), grid=False)
     with pytest.raises(p3d.P3DError):
@@ -622,7 +772,9 @@ def test_fuzz_random_scenes_path_tracer(seed, tmp_path):
 
 
 def test_bench_contract_json_line():
-    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline`."""
+    """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline`.  The headline value is
+    the LITERAL frame (bit-identical to the reference's order); the roofline is a bound (frac <= 1 whenever the PMC
+    summary of this workload matches the kernel sources, null otherwise — stale counters are not quoted)."""
     import json
     import subprocess
     import sys
@@ -634,16 +786,46 @@ def test_bench_contract_json_line():
     assert len(lines) == 1
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "frame", "per_pixel_stack"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["vs_baseline"] is None
     assert d["config"]["rays_per_frame"] == 4944908 and "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["stack_mode"] == "literal" and d["frame"]["handoff"]["redone"] == 9995
+    assert d["frame"]["cold_kernel_ms"] >= d["frame"]["kernel_ms"] * 0.9
     rf = d["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["bound"] == "valu_issue" and rf["unit"] == "Gwave-instr/s" and abs(rf["peak"] - 614.4) < 1e-6
+    if rf["frac"] is not None:
+        assert 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+        assert 0 < rf["hbm"]["frac"] <= 1.0 and rf["traffic"] > 0
+    else:
+        assert "PMC summary" in rf["source"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
-    assert d["value"] > 100 * cb["value"]
+    assert cb["one_socket"]["cores"] >= 1 and cb["one_socket"]["value"] > 0
+    assert d["value"] > 100 * cb["value"] and d["per_pixel_stack"]["value"] > d["value"]
+
+
+def test_two_ranks_on_one_gpu_gather_the_single_gpu_frame():
+    """The N > 1 path of bench.py end to end, as the driver launches it (torch.distributed.run, one process per rank),
+    rehearsed with two ranks sharing the one GPU of this box and a host-staged gloo gather: stripes with halo chains
+    (P3D_STACK_LITERAL), one collective per frame of float RGB + hit IDs, de-interleave on rank 0 — and the gathered
+    frame must equal, bit for bit, the frame one GPU renders alone."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "tri100k",
+           "--gather", "f32", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["stack_mode"] == "literal"
+    assert "gathered frame vs single-GPU frame: ok" in d["config"]["parallelism"], d["config"]["parallelism"]
+    assert d["config"]["rays_per_frame"] == 11546584  # both ranks' rays = the whole frame's
 
 
 def test_pow_spec_matches_libm_after_float_rounding(tmp_path):
