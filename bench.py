@@ -34,6 +34,8 @@ sys.path.insert(0, ROOT)
 
 CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: max clock
 SIMDS = 256 * 4        # 256 CUs x 4 SIMDs
+VALU_CYCLES = 2        # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md "Wave scheduling";
+#                        4 cycles is what ONE wave alone sustains, and what round 1 mistook for the SIMD's rate)
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -344,9 +346,9 @@ def main():
         dominant = "whitted_kernel" if whitted else "pt_kernel"
         dom_ms = pass1_ms if literal else kernel_ms
         alg_gbps = alg_bytes_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # The ceiling that applies (DESIGN.md "Measurement"): the scene is LDS- or L2-resident, so HBM serves the
-        # framebuffer only.  What bounds the dominant kernel is instruction issue: a wave64 VALU instruction holds its
-        # SIMD for 4 cycles, 1024 SIMDs at 2.4 GHz.  Instruction and HBM byte counts come from the rocprofv3 PMC passes
+        # The nearest ceiling (DESIGN.md "Measurement"): the scene is LDS- or L2-resident, so HBM serves the
+        # framebuffer only.  What the dominant kernel spends is instruction issue: a wave64 VALU instruction takes its
+        # SIMD-32 for 2 cycles, 1024 SIMDs at 2.4 GHz = 1228.8 G wave-instructions/s.  Instruction and HBM byte counts come from the rocprofv3 PMC passes
         # of this workload committed under profiles/r02/ — quoted only if taken from exactly these kernel sources.
         summary, src = pmc_summary(workload, args.stack_mode) if world == 1 else (None, "PMC summaries are per single-GPU workload")
         roof = {"kernel": dominant, "kernel_ms": round(dom_ms, 4),
@@ -356,7 +358,7 @@ def main():
             k = summary["dominant"]
             insts = k["SQ_INSTS_VALU"]
             achieved = insts / (dom_ms * 1e-3) / 1e9  # G wave-instructions / s
-            peak = SIMDS * CLOCK_HZ / 4 / 1e9
+            peak = SIMDS * CLOCK_HZ / VALU_CYCLES / 1e9
             traffic = k.get("hbm_bytes")
             roof.update({"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "Gwave-instr/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -365,7 +367,7 @@ def main():
                          "wave_instructions_valu": int(insts), "lane_utilisation": k.get("lane_utilisation"),
                          "rocprof_avg_ms": k.get("avg_ms"), "source": src})
         else:
-            roof.update({"bound": "valu_issue", "achieved": None, "peak": round(SIMDS * CLOCK_HZ / 4 / 1e9, 1), "unit": "Gwave-instr/s",
+            roof.update({"bound": "valu_issue", "achieved": None, "peak": round(SIMDS * CLOCK_HZ / VALU_CYCLES / 1e9, 1), "unit": "Gwave-instr/s",
                          "frac": None, "traffic": None, "source": src})
         out = {
             "metric": "Mrays/s (primary+secondary)", "value": round(value, 1), "unit": "Mrays/s",

@@ -254,7 +254,10 @@ typedef struct p3d_tile {
 } p3d_tile;
 
 /* Counters of one call.  A "ray" is one traversal query (closest-hit or
- * any-hit).  The test counters feed the algorithmic-bytes figure of DESIGN.md. */
+ * any-hit).  The test counters feed the algorithmic-bytes figure of DESIGN.md.
+ * Under P3D_STACK_LITERAL over the BVH the ray / test counters are those of the first, speculative pass over all
+ * pixels (every pixel on an empty stack, zero-weight reflection rays included); the work the hand-off adds is reported
+ * by the handoff_* fields.  P3D_STACK_PER_PIXEL counts query by query what the final frame traced. */
 typedef struct p3d_stats {
   uint64_t rays_primary;
   uint64_t rays_shadow;
@@ -340,6 +343,9 @@ int p3d_render_tile(p3d_scene* scene, const p3d_config* cfg, const p3d_tile* til
  * stream) and the call returns without synchronising unless `stats` is non-NULL
  * (then it waits for the kernel and fills kernel_ms and, with
  * cfg->collect_stats, the counters).
+ * All launches on ONE scene share its scratch (level records, stack spill area, hit_stack hand-off records, work lists,
+ * counters): enqueue them on one stream, or order the streams with events; two renders of the same scene in flight at
+ * once on different streams would overwrite each other's records.  Different scenes are independent.
  */
 int p3d_render_tile_device(p3d_scene* scene, const p3d_config* cfg, const p3d_tile* tile,
                            float* d_rgb, int32_t* d_hit_id, uint8_t* d_rgb8,

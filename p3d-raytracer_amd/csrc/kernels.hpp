@@ -23,6 +23,11 @@
 // trade registers for waves.  100k triangles 1024x1024 / 2048x2048 with 16 / 12 / 12 / 10 / 8 LDS stack entries:
 // 4 waves (111 VGPRs) 8.44 / 22.9 ms, 5 (96) 7.69 / 20.7, 6 (80 VGPRs, 46 spilled dwords) 7.26 / 19.4,
 // 7 (72) 7.40 / 18.7, 8 (64) 7.37 / 18.7.
+// The work-list launches of the hit_stack hand-off (LIT == 2) are short lists of unrelated deep pixels: every wave waits
+// on its own dependent chain, so what counts is how many waves are resident at once, not registers per wave.
+#ifndef P3D_LIST_WAVES
+#define P3D_LIST_WAVES 4
+#endif
 #ifndef P3D_WHITTED_GLOBAL_WAVES
 #define P3D_WHITTED_GLOBAL_WAVES 6
 #endif
@@ -384,7 +389,7 @@ __device__ __forceinline__ float4 first_closest_hit(const RenderParams& P, const
 // with the predecessor's leftover, re-trace the first closest hit if the list entry asks for it, and render the unit again
 // if that hit changed.
 template <int ACCEL, bool LDS, bool STATS, bool AA, bool SPILL = !LDS, int SUB = 1, int LIT = 0>
-__global__ void __launch_bounds__(kBlock, (LDS || AA || LIT == 2) ? P3D_WHITTED_WAVES : P3D_WHITTED_GLOBAL_WAVES) whitted_kernel(const RenderParams P) {
+__global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || AA) ? P3D_WHITTED_WAVES : P3D_WHITTED_GLOBAL_WAVES)) whitted_kernel(const RenderParams P) {
   static_assert(SUB == 1 || AA, "four lanes per pixel need more than one sample per pixel");
   static_assert(LIT == 0 || (ACCEL == P3D_ACCEL_BVH && SUB == 1), "only the BVH has a stack to hand on; one lane per pixel");
   extern __shared__ float4 smem[];

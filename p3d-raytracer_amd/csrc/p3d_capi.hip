@@ -83,7 +83,7 @@ struct SchedEntry {
 };
 constexpr uint32_t kWfHistWords = kWfBins + 32;  // bin counts of one level + the total, padded to a 128-byte multiple
 #ifndef P3D_REDO_LANES
-#define P3D_REDO_LANES 16
+#define P3D_REDO_LANES 4
 #endif
 // list entries per wave of the first work-list launch; P3D_REDO_LANES in the environment overrides it (experiments)
 inline uint32_t redo_lanes() {
@@ -883,12 +883,15 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     P.rgb = d_rgb; P.hit_id = d_hit; P.rgb8 = d_rgb8;
     P.sched = nullptr; P.tile_cost = nullptr;
     // workgroups of a work-list launch: far fewer units than pixels are expected (grid-stride loop for the rest)
-    const uint32_t wide = std::max<uint32_t>(1, std::min<uint32_t>(max_threads / kBlock, std::min<uint32_t>(2048, std::max<uint32_t>(64, H.n_units / 1024))));
+    // (one workgroup per 64 pixels at most: with few list entries per wave a list of 1 % of the pixels still gets a wave
+    // per chunk; workgroups without a chunk leave at once)
+    const uint32_t wide = std::max<uint32_t>(1, std::min<uint32_t>(max_threads / kBlock, std::max<uint32_t>(64, H.n_units / kBlock)));
     for (int round = 0; round < 3; ++round) {
       H.list_in = ho_list[round]; H.n_in = ho_counters + kHoListA + round;
       H.list_out = ho_list[round + 1]; H.n_out = ho_counters + kHoListA + round + 1;
       H.persistent = round == 2 ? 1u : 0u;
-      // round 0 renders unrelated deep pixels: 16 per wave diverge less than 64 (measured: DESIGN.md)
+      // round 0 renders unrelated deep pixels: every wave waits on its own dependent chain, and few pixels per wave
+      // diverge less (4 per wave at 4 waves per SIMD: profiles/r02/experiments/README.md)
       H.lanes = round == 0 ? redo_lanes() : kBlock;
       const uint32_t blocks = round == 2 ? 1u : wide;
       P.level_stride = blocks * kBlock;

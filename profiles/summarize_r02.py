@@ -32,7 +32,13 @@ def short(name):
     return re.sub(r"\(.*$", "", name.replace("void p3d::", "").replace("p3d::", "")).strip()
 
 
-(stats_csv,) = glob.glob(src + "/trace/*/*_kernel_stats.csv")
+def newest(pattern):
+    """a pass directory may hold the output of an earlier run of the recipe as well (gpurun merges): take the latest"""
+    files = glob.glob(pattern)
+    return max(files, key=os.path.getmtime) if files else None
+
+
+stats_csv = newest(src + "/trace/*/*_kernel_stats.csv")
 shutil.copy(stats_csv, os.path.join(dst, tag + "_kernel_stats.csv"))
 for f in ("bench_under_rocprof.json", "bench_plain.json"):
     if os.path.exists(os.path.join(src, f)):
@@ -42,7 +48,10 @@ for row in csv.DictReader(open(stats_csv)):
     kernels[short(row["Name"])] = {"calls": int(row["Calls"]), "avg_ms": float(row["AverageNs"]) / 1e6,
                                     "total_ms": float(row["TotalDurationNs"]) / 1e6, "counters": {}}
 vals = {}
-for path in glob.glob(src + "/pmc_*/*/*_counter_collection.csv"):
+for pass_dir in sorted(glob.glob(src + "/pmc_*")):
+    path = newest(pass_dir + "/*/*_counter_collection.csv")
+    if not path:
+        continue
     for row in csv.DictReader(open(path)):
         vals.setdefault((short(row["Kernel_Name"]), row["Counter_Name"]), []).append(float(row["Counter_Value"]))
 for (k, c), v in sorted(vals.items()):

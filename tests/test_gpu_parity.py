@@ -793,7 +793,7 @@ def test_bench_contract_json_line():
     assert d["config"]["stack_mode"] == "literal" and d["frame"]["handoff"]["redone"] == 9995
     assert d["frame"]["cold_kernel_ms"] >= d["frame"]["kernel_ms"] * 0.9
     rf = d["roofline"]
-    assert rf["bound"] == "valu_issue" and rf["unit"] == "Gwave-instr/s" and abs(rf["peak"] - 614.4) < 1e-6
+    assert rf["bound"] == "valu_issue" and rf["unit"] == "Gwave-instr/s" and abs(rf["peak"] - 1228.8) < 1e-6
     if rf["frac"] is not None:
         assert 0 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
         assert 0 < rf["hbm"]["frac"] <= 1.0 and rf["traffic"] > 0
