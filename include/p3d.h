@@ -255,9 +255,11 @@ typedef struct p3d_tile {
 
 /* Counters of one call.  A "ray" is one traversal query (closest-hit or
  * any-hit).  The test counters feed the algorithmic-bytes figure of DESIGN.md.
- * Under P3D_STACK_LITERAL over the BVH the ray / test counters are those of the first, speculative pass over all
- * pixels (every pixel on an empty stack, zero-weight reflection rays included); the work the hand-off adds is reported
- * by the handoff_* fields.  P3D_STACK_PER_PIXEL counts query by query what the final frame traced. */
+ * They count what the FINAL frame traced, query by query, as the reference's serial loop would: under
+ * P3D_STACK_LITERAL a pixel that was rendered again counts once, with its last render, a pixel whose first closest hit
+ * was only re-traced on its predecessor's leftover counts that query's tests as re-traced (the stale entries it
+ * visits), and the zero-weight reflection rays are rays.  max_stack is the deepest stack of anything that was traced,
+ * speculative passes included.  What the hand-off cost on top is in the handoff_* fields and handoff_ms. */
 typedef struct p3d_stats {
   uint64_t rays_primary;
   uint64_t rays_shadow;

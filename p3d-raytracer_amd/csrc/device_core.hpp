@@ -167,6 +167,8 @@ template <bool ON>
 struct Counters {
   __device__ __forceinline__ void add(int, uint32_t = 1) {}
   __device__ __forceinline__ void stack_depth(int) {}
+  __device__ __forceinline__ void clear() {}
+  __device__ __forceinline__ uint32_t get(int) const { return 0; }
 };
 template <>
 struct Counters<true> {
@@ -174,6 +176,7 @@ struct Counters<true> {
   __device__ __forceinline__ void clear() {
     for (int i = 0; i < kNumStats; ++i) c[i] = 0;
   }
+  __device__ __forceinline__ uint32_t get(int slot) const { return c[slot]; }
   __device__ __forceinline__ void add(int slot, uint32_t n = 1) { c[slot] += n; }
   __device__ __forceinline__ void stack_depth(int d) {
     if ((uint32_t)d > c[kMaxStack]) c[kMaxStack] = d;

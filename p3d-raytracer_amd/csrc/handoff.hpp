@@ -60,7 +60,13 @@ struct Handoff {
   uint32_t* n_in;
   uint32_t* n_out;
   uint32_t* counters;        // kHoNumCounters words
+  // collect_stats under P3D_STACK_LITERAL: the counters of every unit's CURRENT render (so that a unit rendered again
+  // replaces its first pass) and, within them, those of its first closest hit (which a new predecessor leftover changes
+  // even when the hit itself stays: the stale entries are visited).  Summed over the tile's pixels at the end.
+  uint32_t* ucount;          // [kNumStats][n_units]
+  uint32_t* uch0;            // [kCh0Counters][n_units]
 };
+constexpr int kCh0Counters = 5;  // node, sphere, triangle, box, plane tests of the first closest hit
 
 // highest set bit in [lo, i), -1: none
 __device__ inline int find_prev_bit(const uint32_t* bits, uint32_t lo, uint32_t i) {

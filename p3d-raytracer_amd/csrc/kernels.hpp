@@ -353,6 +353,45 @@ __device__ __forceinline__ void seed_stack(Stack& st, const Handoff& H, uint32_t
     push<SPILL>(st, v.x, __uint_as_float(v.y), ct);
   }
 }
+// collect_stats under P3D_STACK_LITERAL (handoff.hpp: ucount / uch0).  The deepest stack goes straight to the global
+// maximum: it is taken over everything that was traced, speculative passes included.
+template <bool STATS>
+__device__ __forceinline__ void store_unit_counters(const Handoff& H, uint32_t unit, const Counters<STATS>& ct, const uint32_t* ch0,
+                                                    unsigned long long* stats) {
+  if (!STATS) return;
+  for (int s = 0; s < kNumStats; ++s)
+    if (s != kMaxStack) H.ucount[(size_t)s * H.n_units + unit] = ct.get(s);
+  for (int k = 0; k < kCh0Counters; ++k) H.uch0[(size_t)k * H.n_units + unit] = ch0[k];
+  atomicMax(&stats[kMaxStack], (unsigned long long)ct.get(kMaxStack));
+}
+// a unit whose first closest hit was re-traced on a new leftover and came out the same: only that query's tests change
+template <bool STATS>
+__device__ __forceinline__ void replace_ch0_counters(const Handoff& H, uint32_t unit, const Counters<STATS>& cc, unsigned long long* stats) {
+  if (!STATS) return;
+  for (int k = 0; k < kCh0Counters; ++k) {
+    const size_t at = (size_t)k * H.n_units + unit;
+    const uint32_t now = cc.get(kNodeTests + k);
+    H.ucount[(size_t)(kNodeTests + k) * H.n_units + unit] += now - H.uch0[at];
+    H.uch0[at] = now;
+  }
+  atomicMax(&stats[kMaxStack], (unsigned long long)cc.get(kMaxStack));
+}
+// sum of the unit counters over the pixels of the tile (halo units are not pixels of the tile)
+__global__ void __launch_bounds__(256) ucount_reduce_kernel(const Handoff H, uint32_t w, unsigned long long* stats) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t n_pix = w * H.rows;
+  for (int s = 0; s < kNumStats; ++s) {
+    if (s == kMaxStack) continue;
+    unsigned long long v = 0;
+    for (uint32_t p = i; p < n_pix; p += gridDim.x * 256) {
+      const uint32_t unit = (p / w) * H.row_units + H.halo + (p % w);
+      v += H.ucount[(size_t)s * H.n_units + unit];
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&stats[s], v);
+  }
+}
+
 __device__ __forceinline__ bool same_first(float4 a, float4 b) {
   return __float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) &&
          __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
@@ -481,13 +520,20 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
       bool unit_touched = false;
       float4 unit_first = make_float4(0.f, 0.f, 0.f, 0.f);
       uint32_t unit_first_sample = 0;
+      uint32_t unit_ch0[kCh0Counters] = {0, 0, 0, 0, 0};
+      if (STATS && LIT != 0) ct.clear();  // LITERAL: counters per unit (store_unit_counters), not per lane
       if (LIT == 2 && active) {  // seed with the predecessor's leftover; re-trace the first closest hit if asked to
         seed_stack<SPILL>(st, H, pred, pred_slot_count, ct);
         if (flags & 1u) {
           if (H.count) atomicAdd(&H.counters[kHoChecked], 1u);
           const float4 now = first_closest_hit<SPILL>(P, sc, st, up.x, up.y, AA ? H.first_sample[unit] : 0u, ct);
-          if (same_first(now, H.first[unit])) active = false;  // nothing this unit computes can differ
-          else seed_stack<SPILL>(st, H, pred, pred_slot_count, ct);
+          if (same_first(now, H.first[unit])) {  // nothing this unit computes can differ
+            active = false;
+            replace_ch0_counters<STATS>(H, unit, ct, P.stats);
+          } else {
+            seed_stack<SPILL>(st, H, pred, pred_slot_count, ct);
+          }
+          if (STATS) ct.clear();
         }
         if (active && H.count) atomicAdd(&H.counters[kHoRedone], 1u);
       }
@@ -600,6 +646,10 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
           }
           H.meta[unit] = meta;
         }
+        if (LIT != 0 && STATS) {
+          if (up.halo) ct.clear();  // a halo pixel is rendered for its leftover, it is not a pixel of this tile
+          store_unit_counters<STATS>(H, unit, ct, unit_ch0, P.stats);
+        }
         if (LIT == 2) {  // a changed leftover goes to the unit's other slot and sends the successor to the next round
           const uint32_t meta = H.meta[unit];
           const uint32_t cur = (meta >> 16) & 1u, cnt = meta & 0xffffu;
@@ -630,7 +680,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
     uint4* tl = list_in; list_in = list_out; list_out = tl;
     uint32_t* tn = n_in_p; n_in_p = n_out_p; n_out_p = tn;
   }
-  if (STATS) flush_stats<STATS>(ct, P.stats);
+  if (STATS && LIT == 0) flush_stats<STATS>(ct, P.stats);  // LITERAL: ucount_reduce_kernel
   if (LIT != 2 && !halo_block) record_tile_cost(P, tx, ty, t_begin);
   P3D_TL_END()
 }
@@ -794,9 +844,21 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
       bool unit_touched = false;
       float4 unit_first = make_float4(0.f, 0.f, 0.f, 0.f);
       uint32_t unit_first_sample = 0;
+      uint32_t unit_ch0[kCh0Counters] = {0, 0, 0, 0, 0};
       F3 chain_result = f3(0, 0, 0);
 #include "whitted_level.inc"
       (void)n_deferred; (void)unit_first_sample;
+      if (STATS && LIT == 1) {  // counters per unit, accumulated level by level (handoff.hpp: ucount)
+        if (up.halo) ct.clear();
+        if (level == 0) {
+          store_unit_counters<STATS>(H, unit, ct, unit_ch0, P.stats);
+        } else {
+          for (int s = 0; s < kNumStats; ++s)
+            if (s != kMaxStack) H.ucount[(size_t)s * H.n_units + unit] += ct.get(s);
+          atomicMax(&P.stats[kMaxStack], (unsigned long long)ct.get(kMaxStack));
+        }
+        ct.clear();
+      }
       if (level == 0 && !up.halo && P.hit_id) P.hit_id[(size_t)up.r * P.w + up.c] = first_hit;
       if (chain_ended) {
         P.wf_final[unit] = make_float4(chain_result.x, chain_result.y, chain_result.z, __uint_as_float(level));
@@ -836,7 +898,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
     }
     if (level == 0) break;
   }
-  if (STATS) flush_stats<STATS>(ct, P.stats);
+  if (STATS && LIT == 0) flush_stats<STATS>(ct, P.stats);
 }
 
 // counts per bin -> first slot of each bin (exclusive prefix sum, in place); hist[kWfBins] = number of rays
@@ -951,7 +1013,7 @@ __global__ void __launch_bounds__(kBlock) halo_find_kernel(const RenderParams P,
 
 // Round 1 of the hand-off for a whole launch: every unit that touched the stack and whose predecessor left something
 // re-traces its first closest hit on that leftover; the units whose hit changed go on the work list of the redo launch.
-template <bool LDS, bool SPILL>
+template <bool LDS, bool SPILL, bool STATS = false>
 __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParams P) {
   extern __shared__ float4 smem[];
   uint32_t tx = 0, ty = 0;
@@ -980,7 +1042,8 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
   DevScene sc = P.sc;
   stage_scene<LDS>(sc, P, smem);
   if (!need) return;
-  Counters<false> ct;
+  Counters<STATS> ct;
+  ct.clear();
   Stack st;
   st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
   st.spill = P.spill + (blockIdx.x * kBlock + lane);
@@ -994,6 +1057,8 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
   const float4 now = first_closest_hit<SPILL>(P, sc, st, up.x, up.y, P.antialiasing ? H.first_sample[unit] : 0u, ct);
   if (!same_first(now, H.first[unit]))
     handoff_append(H.list_out, H.n_out, H.list_cap, H.counters, make_uint4(unit, (uint32_t)pred, slot_count, 0u));
+  else
+    replace_ch0_counters<STATS>(H, unit, ct, P.stats);
 }
 
 // ---------------------------------------------------------------------------

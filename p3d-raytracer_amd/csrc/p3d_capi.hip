@@ -118,7 +118,7 @@ struct p3d_scene {
   float device_bvh_ms = 0;  // GPU time of lbvh::build, 0 for an uploaded tree
   Scratch levels, spill, deferred, wf_rays, wf_keys, wf_sorted, wf_final, out_rgb, out_hit, out_rgb8, q_in, q_out;
   // P3D_STACK_LITERAL (csrc/handoff.hpp): leftovers, per-unit records, work lists, counters
-  Scratch ho_entries, ho_meta, ho_first, ho_first_sample, ho_touched, ho_lists, ho_counters, ho_row_chain, ho_halo_pix;
+  Scratch ho_entries, ho_meta, ho_first, ho_first_sample, ho_touched, ho_lists, ho_counters, ho_row_chain, ho_halo_pix, ho_ucount;
   std::vector<int32_t> ho_chain_key;     // tile the row_chain flags on the device were computed for
   float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};  // box of BVH node 0 (bins of the per-level ray queue)
   bool zero_weight_reflections = false;  // some material is transmissive AND reflective (main.cpp:282,290-300)
@@ -152,7 +152,7 @@ void p3d_scene_destroy(p3d_scene* s) {
   }
   s->levels.release(); s->spill.release(); s->deferred.release(); s->wf_rays.release(); s->wf_keys.release(); s->wf_sorted.release(); s->wf_final.release(); s->out_rgb.release(); s->out_hit.release();
   s->ho_entries.release(); s->ho_meta.release(); s->ho_first.release(); s->ho_first_sample.release(); s->ho_touched.release();
-  s->ho_lists.release(); s->ho_counters.release(); s->ho_row_chain.release(); s->ho_halo_pix.release();
+  s->ho_lists.release(); s->ho_counters.release(); s->ho_row_chain.release(); s->ho_halo_pix.release(); s->ho_ucount.release();
   if (s->d_status) (void)hipFree(s->d_status);
   s->out_rgb8.release(); s->q_in.release(); s->q_out.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -430,7 +430,7 @@ hipError_t launch_accel(bool pt, bool aa, bool sub4, bool lds_scene, bool stats,
   return stats ? launch_one<ACCEL, false, true>(pt, aa, sub4, P, blocks, lds, st) : launch_one<ACCEL, false, false>(pt, aa, sub4, P, blocks, lds, st);
 }
 
-// P3D_STACK_LITERAL launches (BVH only).  lit 1: pass 1; lit 2: work-list launch (no counters).
+// P3D_STACK_LITERAL launches (BVH only).  lit 1: pass 1; lit 2: work-list launch; lit 0: the check launch.
 template <bool LDS, bool SPILL>
 hipError_t launch_literal_variant(int lit, bool aa, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
   constexpr int A = P3D_ACCEL_BVH;
@@ -440,10 +440,14 @@ hipError_t launch_literal_variant(int lit, bool aa, bool stats, const RenderPara
     else if (stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, false, SPILL, 1, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
     else hipLaunchKernelGGL((whitted_kernel<A, LDS, false, false, SPILL, 1, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
   } else if (lit == 2) {
-    if (aa) hipLaunchKernelGGL((whitted_kernel<A, LDS, false, true, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
+    if (aa && stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, true, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
+    else if (aa) hipLaunchKernelGGL((whitted_kernel<A, LDS, false, true, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
+    else if (stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, false, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
     else hipLaunchKernelGGL((whitted_kernel<A, LDS, false, false, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
+  } else if (stats) {
+    hipLaunchKernelGGL((handoff_check_kernel<LDS, SPILL, true>), dim3(blocks), dim3(kBlock), lds, st, P);
   } else {
-    hipLaunchKernelGGL((handoff_check_kernel<LDS, SPILL>), dim3(blocks), dim3(kBlock), lds, st, P);
+    hipLaunchKernelGGL((handoff_check_kernel<LDS, SPILL, false>), dim3(blocks), dim3(kBlock), lds, st, P);
   }
   return hipGetLastError();
 }
@@ -758,6 +762,11 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       H.row_chain = (const uint8_t*)s->ho_row_chain.p;
       H.halo_pix = (const uint32_t*)s->ho_halo_pix.p;
     }
+    if (literal && want_counts) {  // per-unit counters: a unit rendered again replaces its first pass (handoff.hpp)
+      if (int rc = s->ho_ucount.ensure((size_t)(kNumStats + kCh0Counters) * H.n_units * sizeof(uint32_t))) return rc;
+      H.ucount = (uint32_t*)s->ho_ucount.p;
+      H.uch0 = H.ucount + (size_t)kNumStats * H.n_units;
+    }
     H.list_cap = H.n_units;
     H.count = want_counts ? 1u : 0u;
     H.max_rounds = H.n_units + 2;
@@ -896,8 +905,12 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       const uint32_t blocks = round == 2 ? 1u : wide;
       P.level_stride = blocks * kBlock;
       P.tile_blocks = blocks;
-      const hipError_t e = launch_literal(2, cfg->antialiasing != 0, lds_scene, false, P, blocks, lds_bytes, st);
+      const hipError_t e = launch_literal(2, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
       if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("hand-off kernel launch: ") + hipGetErrorString(e));
+    }
+    if (want_counts) {
+      hipLaunchKernelGGL(ucount_reduce_kernel, dim3(256), dim3(256), 0, st, H, (uint32_t)tile->w, s->d_stats);
+      P3D_HIP(hipGetLastError());
     }
   }
   if (stats) return finish_stats(s, st, stats, literal);

@@ -3,8 +3,9 @@
 
   python tests/fuzz_campaign.py [--whitted N] [--pt M] [--start S]
 
-Same generator and same bars as test_fuzz_random_scenes_* in test_gpu_parity.py, over many more
-seeds and over scene sizes on both sides of the LDS-staging limit.  Prints one line per failing
+Same generator and same bars as test_fuzz_random_scenes_* in test_gpu_parity.py (check_whitted: the default
+P3D_STACK_LITERAL frame over the BVH bit-identical to the oracle's serial order, then the per-pixel stack with every
+counter), over many more seeds and over scene sizes on both sides of the LDS-staging limit.  Prints one line per failing
 (seed, accel) and a summary; exit code 1 if anything failed.  Test infrastructure: uses oracle/."""
 import argparse
 import os
@@ -18,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import p3d_amd as p3d  # noqa: E402
 from fuzz_scenes import random_scene  # noqa: E402
 from oracle import binding as ob  # noqa: E402
-from test_gpu_parity import oracle_cfg_like  # noqa: E402
+from test_gpu_parity import check_whitted, oracle_cfg_like  # noqa: E402
 
 COUNTERS = ("rays", "node_tests", "sphere_tests", "tri_tests", "box_tests", "plane_tests")
 
@@ -43,22 +44,14 @@ def main():
                 continue
             kw = dict(antialiasing=1, spp_sqrt=2, soft_shadows=1, depth_of_field=k % 2, sample_disk=(k // 2) % 2,
                       sample_mode=(k // 4) % 2, seed=k) if k % 5 == 1 else {}
-            cfg = p3d.whitted_config(accel=accel, max_depth=k % 8, collect_stats=1, **kw)
-            rgb, hit, st = dev.render(cfg)
-            o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
-            m = np.isfinite(o_rgb).all(-1)
-            d = float(np.abs(rgb[m] - o_rgb[m]).max()) if m.any() else 0.0
-            worst = max(worst, d)
-            bad = []
-            if not (hit == o_hit).all(): bad.append("hit ids (%d px)" % int((hit != o_hit).sum()))
-            if not (np.isfinite(rgb).all(-1) == m).all(): bad.append("finite mask")
-            if d > 5e-6: bad.append("rgb %.3g" % d)
-            if tuple(getattr(st, c) for c in COUNTERS) != tuple(getattr(o_st, c) for c in COUNTERS): bad.append("counters")
-            if bad:
+            cfg = p3d.whitted_config(accel=accel, max_depth=k % 8, **kw)
+            try:
+                check_whitted(dev, sc, cfg, tol=5e-6, counters=("rays_primary", "rays_shadow", "rays_reflect", "rays_refract") + COUNTERS[1:])
+            except AssertionError as e:
                 fails += 1
-                print("FAIL whitted seed %d accel %d size %d depth %d: %s" % (k, accel, size, k % 8, ", ".join(bad)), flush=True)
+                print("FAIL whitted seed %d accel %d size %d depth %d: %s" % (k, accel, size, k % 8, str(e)[:200]), flush=True)
         if k % 20 == 19:
-            print("whitted %d done, worst |rgb diff| %.3g, failures %d" % (k + 1 - a.start, worst, fails), flush=True)
+            print("whitted %d done, failures %d" % (k + 1 - a.start, fails), flush=True)
     worst_pt = 0.0
     for k in range(a.start, a.start + a.pt):
         size = (1, 3, 10)[k % 3]

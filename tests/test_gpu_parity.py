@@ -66,13 +66,16 @@ COUNTERS = ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "node
 
 def check_whitted(dev, sc, cfg, tol=2e-6, counters=COUNTERS, max_stack=False):
     """cfg as given: for the BVH under P3D_STACK_LITERAL the frame must be bit-identical to the oracle's serial
-    order.  Then (BVH) the per-pixel stack, or (other back ends) the one render there is: frame within `tol` of the
+    order and every ray / test counter equal to the oracle's.  Then (BVH) the per-pixel stack, or (other back ends) the one render there is: frame within `tol` of the
     oracle in the same semantics and every counter equal.  Returns the first render's (rgb, hit, stats)."""
     cfg.collect_stats = 1
     first = dev.render(cfg)
     if literal_applies(cfg):
-        o_rgb, o_hit, _ = sc.render(oracle_cfg_like(cfg))
+        o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
         assert_bit_identical(first[:2], (o_rgb, o_hit), "literal hit_stack")
+        for k in counters:  # what the final frame traced, query by query: redone pixels count once, stale entries visited count
+            assert getattr(first[2], k) == getattr(o_st, k), "literal " + k
+        assert first[2].max_stack >= o_st.max_stack  # (the deepest stack of anything traced, speculative passes included)
         cfg = per_pixel(cfg)
         rgb, hit, st = dev.render(cfg)
     else:
