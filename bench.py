@@ -19,6 +19,11 @@ the reference's serial pixel order (tests/test_gpu_parity.py); `per_pixel_stack`
 emptied at every primary sample (one launch, <= 1e-4 from the reference on sphere scenes, identical on triangle
 scenes).  Rays are counted as the reference's frame has them (one traversal query each).
 
+On one GPU the timed loop keeps two frames in flight (--frames-in-flight 2): frame i is rendered by device scene i % 2 on
+stream i % 2 into buffers of its own — the caller-side way to overlap the latency-bound end of one frame (its slowest
+tiles, the redo launch of the hit_stack hand-off) with the start of the next; every frame is rendered completely, all are
+finished when the timed region ends.  `frame.kernel_ms` is ONE frame on its own (HIP events inside the library).
+
 Prints ONE JSON line on rank 0.  `roofline` and `cpu_baseline` follow DESIGN.md "Measurement".
 """
 import argparse
@@ -50,6 +55,11 @@ def parse():
                          "cfg3/cfg5 = configs[2]/[4] at their full sizes; cfg2w = cfg2 weak-scaled; tri100k / cornell_pt = quick sizes")
     ap.add_argument("--stack-mode", default="literal", choices=["literal", "per_pixel"],
                     help="p3d_config.stack_mode of the timed frames (include/p3d.h)")
+    ap.add_argument("--frames-in-flight", type=int, default=None,
+                    help="N = 1: consecutive frames go round-robin to this many device scenes (each with its own scratch and "
+                         "hand-off records, p3d.h: different scenes are independent) on as many HIP streams, so that the "
+                         "latency-bound tail of frame k (its slowest tiles, the redo launch of the literal hand-off) overlaps "
+                         "the start of frame k+1.  Default 2 on one GPU (1 = every frame waits for the one before), 1 on several.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-order", default="cost", choices=["cost", "frame"],
                     help="p3d_config.tile_order: cost = tiles most-expensive-class first (schedule recorded by the first "
@@ -172,6 +182,11 @@ def main():
     tile = p3d.stripe_tile((res, res), rank, world, stripe_h) if world > 1 else dev.full_tile()
     n_local = tile.w * tile.h
     stream = torch.cuda.current_stream()
+    # frames in flight (N = 1): frame i is rendered by scene i % nfl on stream i % nfl into output buffers of its own
+    nfl = max(1, args.frames_in_flight if args.frames_in_flight is not None else (2 if world == 1 else 1))
+    if world > 1:
+        nfl = 1
+    flight = [(dev, stream)] + [(p3d.DeviceScene(hs, bvh=True, device=dev_index), torch.cuda.Stream()) for _ in range(nfl - 1)]
 
     # Every rank renders ALL outputs of its stripes into HBM: float RGB + hit IDs (one packed
     # allocation, 16 B/px) and the gamma-corrected u8 image (img_Data, 3 B/px).  Rank 0 collects one
@@ -204,12 +219,12 @@ def main():
             p3d.assemble_frame(gathered[slot], (res, res), world, stripe_h, frame_rgb, frame_hit, batch=B)
         last_frame[0] = in_flight[slot] - 1
 
-    def render_into(pair, tile_, cfg_, stats=None, frame=0, scene=None):
+    def render_into(pair, tile_, cfg_, stats=None, frame=0, scene=None, on=None):
         packed, u8 = pair
         n_px = tile_.w * tile_.h
         base_ = packed.data_ptr() + frame * p3d.packed_bytes(n_px)
         (scene or dev).render_device(cfg_, tile_, d_rgb=base_, d_hit=base_ + n_px * 12, d_rgb8=u8.data_ptr() + frame * n_px * 3,
-                                     stream=stream.cuda_stream, stats=stats)
+                                     stream=(on or stream).cuda_stream, stats=stats)
 
     def finish(slot):  # the collective of this slot has to be complete before the buffer is reused
         if handles[slot] is not None:
@@ -225,7 +240,13 @@ def main():
             in_flight[slot], filled[slot] = filled[slot], 0
             sent_seq[slot] = max(sent_seq) + 1
 
+    flight_bufs = [bufs[0]] + [new_bufs() for _ in range(nfl - 1)]
+
     def step(i, cfg_):
+        if nfl > 1:  # one GPU: nothing to gather; the frame goes to the scene, stream and buffers of its slot
+            k = i % nfl
+            render_into(flight_bufs[k], tile, cfg_, scene=flight[k][0], on=flight[k][1])
+            return
         slot, f = (i // B) & 1, i % B
         if f == 0:
             finish(slot)
@@ -273,6 +294,8 @@ def main():
     render_into(bufs[0], small, cfg, stats=p3d.Stats())
     cold = p3d.Stats()
     render_into(bufs[0], tile, cfg, stats=cold)
+    for sc_, st_ in flight[1:]:  # the other slots record their tile schedules outside the timed region too
+        render_into(bufs[0], tile, cfg, stats=p3d.Stats(), scene=sc_, on=st_)
     dt = timed_loop(cfg)
 
     # Launch durations inside the frame, live: HIP events of the library on the launch stream (p3d_stats.kernel_ms /
@@ -313,6 +336,8 @@ def main():
         fresh = p3d.DeviceScene(hs, bvh=True, device=dev_index)
         render_into(bufs[0], small, cfg_pp, stats=p3d.Stats(), scene=fresh)
         render_into(bufs[0], tile, cfg_pp, stats=pp_cold, scene=fresh)
+        for sc_, st_ in flight:
+            render_into(bufs[0], tile, cfg_pp, stats=p3d.Stats(), scene=sc_, on=st_)
         dt_pp = timed_loop(cfg_pp)
         pk = []
         for _ in range(16):
@@ -365,7 +390,10 @@ def main():
                          "hbm": {"achieved_GBps": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None, "peak_GBps": HBM_PEAK_GBPS,
                                  "frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None},
                          "wave_instructions_valu": int(insts), "lane_utilisation": k.get("lane_utilisation"),
-                         "rocprof_avg_ms": k.get("avg_ms"), "source": src})
+                         "rocprof_avg_ms": k.get("avg_ms"), "source": src,
+                         "scope": "the dominant kernel of ONE frame on its own (kernel_ms live from HIP events, rocprof_avg_ms from "
+                                  "the committed trace of `bench.py --frames-in-flight 1`)",
+                         "timed_loop_frac_lower_bound": round(insts / (dt / args.steps) / 1e9 / peak, 4) if world == 1 else None})
         else:
             roof.update({"bound": "valu_issue", "achieved": None, "peak": round(SIMDS * CLOCK_HZ / VALU_CYCLES / 1e9, 1), "unit": "Gwave-instr/s",
                          "frac": None, "traffic": None, "source": src})
@@ -380,6 +408,7 @@ def main():
                        "stack_mode": args.stack_mode if whitted and cfg.accel == p3d.ACCEL_BVH else "n/a (no stack survives a query here)",
                        "outputs_per_rank": "float RGB + hit ID (16 B/px) + u8 image (3 B/px), all written to HBM",
                        "tile_order": args.tile_order,
+                       "frames_in_flight": nfl,
                        "parallelism": "image rows in %d-row stripes, round-robin over %d GPU(s)%s"
                                       % (stripe_h, world,
                                          "; every frame's %s gathered to rank 0 over %s, %d frame(s) per collective, "
@@ -388,7 +417,8 @@ def main():
                                          if world > 1 else "")},
             "frame": {"kernel_ms": round(kernel_ms, 4), "pass1_ms": round(pass1_ms, 4), "handoff_ms": round(handoff_ms, 4),
                       "cold_kernel_ms": round(cold.kernel_ms, 4), "handoff": handoff,
-                      "note": "HIP events of the library on the launch stream; cold = first launch of this scene and config "
+                      "note": "ONE frame on its own: HIP events of the library on the launch stream (ms_per_step is the rate of the "
+                              "timed loop, with frames_in_flight frames overlapping); cold = first launch of this scene and config "
                               "(image order, tile costs recorded), the timed frames use the recorded tile schedule"},
             "roofline": roof,
         }
