@@ -280,7 +280,7 @@ typedef struct p3d_stats {
   uint64_t handoff_checked;  /* pixels whose first closest hit was re-traced on the predecessor's leftover */
   uint64_t handoff_redone;   /* pixels rendered again because that hit changed */
   uint64_t handoff_rounds;   /* rounds until no leftover changed any more */
-  double pass1_ms;           /* of kernel_ms: clear + halo search + the speculative pass over all pixels */
+  double pass1_ms;           /* of kernel_ms: the speculative pass over all pixels (the launches of pass 1 alone) */
   double handoff_ms;         /* of kernel_ms: check, redo and fixed-point launches */
 } p3d_stats;
 
