@@ -395,6 +395,14 @@ def test_chain_per_level_launches_write_the_same_bits(scene, legacy, res, depth,
     assert e.value.code == -3
 
 
+def test_literal_hand_off_across_several_launches():
+    """A frame whose per-thread scratch forces several launches (MAX_DEPTH 1000: 16 KB of level records per thread,
+    512x512 pixels): the hand-off records are numbered over the whole tile, the check and the work lists run once after
+    the last band — the frame must still be the oracle's serial order bit for bit, counters included."""
+    dev, sc = _pair(scene_path("balls_low.p3f"), res=(512, 512), grid=False)
+    check_whitted(dev, sc, p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=1000))
+
+
 def test_sample_loop_backstop_is_an_error_not_a_darker_pixel():
     """The four-lanes-per-pixel kernels hand samples out by ticket inside a wave-uniform loop with a trip bound as
     backstop.  A pixel that ran into the bound would be written with samples missing: the kernel raises a flag and
