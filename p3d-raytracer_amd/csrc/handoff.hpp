@@ -36,6 +36,7 @@ enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoError, kHoListA, 
 constexpr uint32_t kHoErrLeftoverCap = 1u;   // a leftover had more entries than a slot holds
 constexpr uint32_t kHoErrNoFixedPoint = 2u;  // round bound reached
 constexpr uint32_t kHoErrTrips = 4u;         // sample hand-out loop hit its trip bound (SUB = 4 kernels)
+constexpr uint32_t kHoErrList = 8u;          // a work list or a ray queue segment overflowed
 
 struct Handoff {
   uint32_t n_units;     // rows * row_units
@@ -129,7 +130,7 @@ __device__ __forceinline__ bool handoff_touched(const Handoff& H, uint32_t u) { 
 __device__ __forceinline__ void handoff_append(uint4* list, uint32_t* n, uint32_t cap, uint32_t* counters, uint4 e) {
   const uint32_t i = atomicAdd(n, 1u);
   if (i < cap) list[i] = e;
-  else atomicOr(&counters[kHoError], kHoErrLeftoverCap);
+  else atomicOr(&counters[kHoError], kHoErrList);
 }
 
 }  // namespace p3d

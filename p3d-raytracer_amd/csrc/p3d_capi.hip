@@ -536,6 +536,7 @@ int check_status(p3d_scene* s) {
   if (h & kHoErrTrips) what += " sample hand-out loop reached its trip bound (pixels would miss samples);";
   if (h & kHoErrLeftoverCap) what += " a hit_stack leftover outgrew its slot;";
   if (h & kHoErrNoFixedPoint) what += " hit_stack hand-off did not reach a fixed point;";
+  if (h & kHoErrList) what += " a ray queue segment of the per-level launches overflowed;";
   return fail(P3D_ERR_CAPACITY, "device-detected error:" + what);
 }
 
