@@ -69,29 +69,29 @@ struct Handoff {
 };
 constexpr int kCh0Counters = 5;  // node, sphere, triangle, box, plane tests of the first closest hit
 
-// highest set bit in [lo, i), -1: none
-__device__ inline int find_prev_bit(const uint32_t* bits, uint32_t lo, uint32_t i) {
+// highest set bit in [lo, i), -1: none  (host + device: tests/handoff_scan_check.cpp runs these on the CPU)
+__host__ __device__ inline int find_prev_bit(const uint32_t* bits, uint32_t lo, uint32_t i) {
   if (i <= lo) return -1;
   uint32_t w = (i - 1) >> 5;
   const uint32_t wlo = lo >> 5;
   uint32_t word = bits[w] & (0xffffffffu >> (31u - ((i - 1) & 31u)));
   while (true) {
     if (w == wlo) word &= 0xffffffffu << (lo & 31u);
-    if (word) return (int)(w * 32u + 31u - (uint32_t)__clz((int)word));
+    if (word) return (int)(w * 32u + 31u - (uint32_t)__builtin_clz(word));
     if (w == wlo) return -1;
     --w;
     word = bits[w];
   }
 }
 // lowest set bit in [i, hi), -1: none
-__device__ inline int find_next_bit(const uint32_t* bits, uint32_t i, uint32_t hi) {
+__host__ __device__ inline int find_next_bit(const uint32_t* bits, uint32_t i, uint32_t hi) {
   if (i >= hi) return -1;
   uint32_t w = i >> 5;
   const uint32_t whi = (hi - 1) >> 5;
   uint32_t word = bits[w] & (0xffffffffu << (i & 31u));
   while (true) {
     if (w == whi) word &= 0xffffffffu >> (31u - ((hi - 1) & 31u));
-    if (word) return (int)(w * 32u + (uint32_t)__ffs((int)word) - 1u);
+    if (word) return (int)(w * 32u + (uint32_t)__builtin_ffs((int)word) - 1u);
     if (w == whi) return -1;
     ++w;
     word = bits[w];
@@ -99,7 +99,7 @@ __device__ inline int find_next_bit(const uint32_t* bits, uint32_t i, uint32_t h
 }
 
 // the unit whose leftover `u` starts on: the last unit before it that touched the stack (-1: u starts empty)
-__device__ inline int handoff_pred(const Handoff& H, uint32_t u) {
+__host__ __device__ inline int handoff_pred(const Handoff& H, uint32_t u) {
   if (!H.row_chain) return find_prev_bit(H.touched, 0, u);
   uint32_t row = u / H.row_units, i = u;
   while (true) {
@@ -112,7 +112,7 @@ __device__ inline int handoff_pred(const Handoff& H, uint32_t u) {
   }
 }
 // the unit that starts on u's leftover (-1: nobody in this tile does)
-__device__ inline int handoff_succ(const Handoff& H, uint32_t u) {
+__host__ __device__ inline int handoff_succ(const Handoff& H, uint32_t u) {
   if (!H.row_chain) return find_next_bit(H.touched, u + 1, H.n_units);
   uint32_t row = u / H.row_units, i = u + 1;
   while (true) {

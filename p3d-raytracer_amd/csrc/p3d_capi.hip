@@ -774,7 +774,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     }
     H.list_cap = H.n_units;
     H.count = want_counts ? 1u : 0u;
-    H.max_rounds = H.n_units + 2;
+    H.max_rounds = std::min<uint32_t>(H.n_units + 2, 4096);  // a chain of n units is exact after n rounds at the latest; measured: 2.  Beyond the cap: P3D_ERR_CAPACITY
     for (int i = 0; i < 4; ++i) ho_list[i] = (uint4*)s->ho_lists.p + (size_t)i * H.n_units;
     ho_counters = (uint32_t*)s->ho_counters.p;
     H.counters = ho_counters;

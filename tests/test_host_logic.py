@@ -140,3 +140,20 @@ def test_loader_error_paths():
     hs = p3d.HostScene(scene_path("balls_medium.p3f"))   # 11-number `f`: shipped parser stops, 0 objects
     assert hs.arrays()["n_prims"] == 0 and hs.arrays()["n_lights"] == 3
     assert p3d.HostScene(scene_path("balls_medium.p3f"), legacy_f11=True).arrays()["n_prims"] == 93
+
+
+def test_handoff_predecessor_successor_scans(tmp_path):
+    """csrc/handoff.hpp: which unit's leftover a pixel starts on (handoff_pred) and whose start a changed leftover
+    invalidates (handoff_succ) — bit scans over the touched words, cut at rows that start a halo chain — against a
+    unit-by-unit walk over random patterns.  Host build of the same inline functions the kernels use; no GPU."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "handoff_scan_check")
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "p3d-raytracer_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "handoff_scan_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+    assert int(out.stdout.split()[1]) > 100000
