@@ -364,6 +364,18 @@ def main():
             ok = bool(torch.equal(frame_rgb[k].reshape(-1).view(torch.int32), ref_packed[: res * res * 12].view(torch.int32))
                       and torch.equal(frame_hit[k].reshape(-1), ref_packed[res * res * 12:].view(torch.int32)))
         gather_check = "ok" if ok else "MISMATCH"
+        # and what ONE GPU needs for the whole frame (outside the timed region, the other ranks idle): the N = 1 point of
+        # THIS workload, so that the strong-scaling ratio can be read off one line (the driver's N = 1 run is cfg2)
+        for _ in range(2):
+            render_into(ref_pair, full, cfg)
+        torch.cuda.synchronize()
+        n1 = max(1, min(args.steps, 10))
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            render_into(ref_pair, full, cfg)
+        torch.cuda.synchronize()
+        single_gpu = {"ms_per_step": round((time.perf_counter() - t1) / n1 * 1e3, 4), "steps": n1,
+                      "note": "the whole frame on rank 0's GPU alone, one frame at a time, no gather; value = rays_per_frame / this"}
 
     if rank == 0:
         value = rays_total * args.steps / dt / 1e6
@@ -424,6 +436,9 @@ def main():
         }
         if per_pixel:
             out["per_pixel_stack"] = per_pixel
+        if world > 1:
+            single_gpu["value"] = round(rays_total / (single_gpu["ms_per_step"] * 1e-3) / 1e6, 1)
+            out["single_gpu_same_workload"] = single_gpu
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(workload, scene_path, cfg, res)
         print(json.dumps(out))

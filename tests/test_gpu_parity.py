@@ -837,6 +837,8 @@ def test_two_ranks_on_one_gpu_gather_the_single_gpu_frame():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["stack_mode"] == "literal"
     assert "gathered frame vs single-GPU frame: ok" in d["config"]["parallelism"], d["config"]["parallelism"]
     assert d["config"]["rays_per_frame"] == 11546584  # both ranks' rays = the whole frame's
+    one = d["single_gpu_same_workload"]  # the N = 1 point of the same workload, timed on rank 0 outside the timed region
+    assert one["ms_per_step"] > 0 and abs(one["value"] - 11546584 / (one["ms_per_step"] * 1e-3) / 1e6) < 0.01 * one["value"]
 
 
 def test_pow_spec_matches_libm_after_float_rounding(tmp_path):
