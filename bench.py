@@ -19,10 +19,10 @@ the reference's serial pixel order (tests/test_gpu_parity.py); `per_pixel_stack`
 emptied at every primary sample (one launch, <= 1e-4 from the reference on sphere scenes, identical on triangle
 scenes).  Rays are counted as the reference's frame has them (one traversal query each).
 
-On one GPU the timed loop keeps two frames in flight (--frames-in-flight 2): frame i is rendered by device scene i % 2 on
-stream i % 2 into buffers of its own — the caller-side way to overlap the latency-bound end of one frame (its slowest
-tiles, the redo launch of the hit_stack hand-off) with the start of the next; every frame is rendered completely, all are
-finished when the timed region ends.  `frame.kernel_ms` is ONE frame on its own (HIP events inside the library).
+On one GPU the timed loop keeps four frames in flight (--frames-in-flight 4): frame i is rendered by device scene i % 4 on
+stream i % 4 into buffers of its own — the caller-side way to overlap the latency-bound parts of a frame (its slowest
+tiles; the check, redo and fixed-point launches of the hit_stack hand-off, which are short dependent launches) with the
+bulk of the others; every frame is rendered completely, all are finished when the timed region ends.  `frame.kernel_ms` is ONE frame on its own (HIP events inside the library).
 
 Prints ONE JSON line on rank 0.  `roofline` and `cpu_baseline` follow DESIGN.md "Measurement".
 """
@@ -59,7 +59,7 @@ def parse():
                     help="N = 1: consecutive frames go round-robin to this many device scenes (each with its own scratch and "
                          "hand-off records, p3d.h: different scenes are independent) on as many HIP streams, so that the "
                          "latency-bound tail of frame k (its slowest tiles, the redo launch of the literal hand-off) overlaps "
-                         "the start of frame k+1.  Default 2 on one GPU (1 = every frame waits for the one before), 1 on several.")
+                         "the bulk of the following frames.  Default 4 on one GPU (1 = every frame waits for the one before), 1 on several.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-order", default="cost", choices=["cost", "frame"],
                     help="p3d_config.tile_order: cost = tiles most-expensive-class first (schedule recorded by the first "
@@ -183,9 +183,11 @@ def main():
     n_local = tile.w * tile.h
     stream = torch.cuda.current_stream()
     # frames in flight (N = 1): frame i is rendered by scene i % nfl on stream i % nfl into output buffers of its own
-    nfl = max(1, args.frames_in_flight if args.frames_in_flight is not None else (2 if world == 1 else 1))
+    nfl = max(1, args.frames_in_flight if args.frames_in_flight is not None else (4 if world == 1 else 1))
     if world > 1:
         nfl = 1
+    # (slot 0 stays on the default stream: HIP spreads streams over 4 hardware queues, the default stream has one to
+    # itself and the pool streams share the other three — a fourth pool stream would queue behind the first one's launches)
     flight = [(dev, stream)] + [(p3d.DeviceScene(hs, bvh=True, device=dev_index), torch.cuda.Stream()) for _ in range(nfl - 1)]
 
     # Every rank renders ALL outputs of its stripes into HBM: float RGB + hit IDs (one packed

@@ -83,9 +83,13 @@ struct SchedEntry {
 };
 constexpr uint32_t kWfHistWords = kWfBins + 32;  // bin counts of one level + the total, padded to a 128-byte multiple
 #ifndef P3D_REDO_LANES
-#define P3D_REDO_LANES 4
+#define P3D_REDO_LANES 32
 #endif
-// list entries per wave of the first work-list launch; P3D_REDO_LANES in the environment overrides it (experiments)
+// List entries per wave of the first work-list launch (the units rendered again: cfg2 9 995 unrelated deep pixels).
+// Measured on cfg2 (profiles/r02/experiments/README.md §7): 4 per wave = 2 500 waves make that launch 130 µs when the
+// frame is alone on the chip, 32 per wave = 313 waves 160 µs (frame 0.338 -> 0.363 ms); but every one of those waves
+// holds a slot and issues for ~100 µs whatever the number of its active lanes, and with other frames in flight that is
+// what counts: four frames in flight 0.21-0.26 -> 0.13-0.16 ms per frame.  P3D_REDO_LANES in the environment overrides it.
 inline uint32_t redo_lanes() {
   static const uint32_t v = [] {
     const char* e = getenv("P3D_REDO_LANES");
@@ -908,8 +912,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       H.list_in = ho_list[round]; H.n_in = ho_counters + kHoListA + round;
       H.list_out = ho_list[round + 1]; H.n_out = ho_counters + kHoListA + round + 1;
       H.persistent = round == 2 ? 1u : 0u;
-      // round 0 renders unrelated deep pixels: every wave waits on its own dependent chain, and few pixels per wave
-      // diverge less (4 per wave at 4 waves per SIMD: profiles/r02/experiments/README.md)
+      // round 0 renders unrelated deep pixels again; entries per wave: see P3D_REDO_LANES above
       H.lanes = round == 0 ? redo_lanes() : kBlock;
       const uint32_t blocks = round == 2 ? 1u : wide;
       P.level_stride = blocks * kBlock;
