@@ -291,11 +291,10 @@ __device__ __forceinline__ bool aabb_intercepts(F3 mn, F3 mx, const RayS& r, flo
   const float tx_min = ((a >= 0 ? mn.x : mx.x) - r.o.x) * a, tx_max = ((a >= 0 ? mx.x : mn.x) - r.o.x) * a;
   const float ty_min = ((b >= 0 ? mn.y : mx.y) - r.o.y) * b, ty_max = ((b >= 0 ? mx.y : mn.y) - r.o.y) * b;
   const float tz_min = ((c >= 0 ? mn.z : mx.z) - r.o.z) * c, tz_max = ((c >= 0 ? mx.z : mn.z) - r.o.z) * c;
-  float t0, t1;
-  if (all_finite) {
-    t0 = __builtin_fmaxf(__builtin_fmaxf(tx_min, ty_min), tz_min);
-    t1 = __builtin_fminf(__builtin_fminf(tx_max, ty_max), tz_max);
-  } else {
+  // the common case falls through (one v_max3 / v_min3); the select chains sit out of line
+  float t0 = __builtin_fmaxf(__builtin_fmaxf(tx_min, ty_min), tz_min);
+  float t1 = __builtin_fminf(__builtin_fminf(tx_max, ty_max), tz_max);
+  if (__builtin_expect(!all_finite, 0)) {
     t0 = max3_ref(tx_min, ty_min, tz_min);
     t1 = min3_ref(tx_max, ty_max, tz_max);
   }
@@ -384,6 +383,7 @@ __device__ __forceinline__ F3 get_normal(const Geom& g, const float4* normals, F
 //   bit 31 = leaf, bits 30..28 = object count of a leaf (<= 7), bits 27..0 = left child
 //   (inner) or first leaf slot (leaf).
 constexpr uint32_t kDescLeaf = 0x80000000u;
+constexpr uint32_t kDescDone = 0xffffffffu;  // traversal state "no node left"; never a descriptor (it would be a leaf of 7 objects at slot 2^28 - 1)
 __device__ __host__ __forceinline__ uint32_t desc_index(uint32_t d) { return d & 0x0fffffffu; }
 __device__ __host__ __forceinline__ uint32_t desc_count(uint32_t d) { return (d >> 28) & 7u; }
 
@@ -405,18 +405,20 @@ __device__ __forceinline__ NodeRec load_node(const float4* nodes, uint32_t i) {
 // is always on a leaf).  The stack holds packed child descriptors, so a pop needs no node
 // fetch.
 
-// bvh.cpp:256-265: pop until an entry is nearer than the best hit; false = stack exhausted
+// bvh.cpp:256-265: pop until an entry is nearer than the best hit; kDescDone = stack exhausted.  One loop condition
+// (`more`) and no exit from the middle: the compiler's loop then needs one lane mask instead of three.
 template <bool SPILL>
-__device__ __forceinline__ bool pop_closer(Stack& st, float tmin, uint32_t& desc) {
-  while (st.sp > 0) {
+__device__ __forceinline__ uint32_t pop_closer(Stack& st, float tmin) {
+  uint32_t desc = kDescDone;
+  bool more = st.sp > 0;
+  while (more) {
     --st.sp;
     const uint2 e = stack_read<SPILL>(st, st.sp);
-    if (__uint_as_float(e.y) < tmin) {
-      desc = e.x;
-      return true;
-    }
+    const bool take = __uint_as_float(e.y) < tmin;
+    if (take) desc = e.x;
+    more = !take && st.sp > 0;
   }
-  return false;
+  return desc;
 }
 
 // Closest hit.  `ray` is the traversal's private copy (bvh.cpp:198 takes Ray by value).
@@ -432,11 +434,12 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
   ct.add(kNodeTests);
   if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, false)) return -1;  // stale entries stay (Q2)
   if (root_passed) *root_passed = true;
+  // The traversal state is ONE word: the descriptor of the node the lane stands on, or kDescDone (leaf bit set, so
+  // that a finished lane also falls out of the descend loop): fewer lane masks for the compiler to carry round the loops.
   uint32_t desc = __float_as_uint(root.lo.w);
-  bool walking = true;
-  while (walking) {
+  while (desc != kDescDone) {
     // ---- descend: bvh.cpp:208-239 ----
-    while (walking && !(desc & kDescLeaf)) {
+    while (!(desc & kDescLeaf)) {
       const uint32_t index = desc_index(desc);
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
       float l_t, r_t;
@@ -452,10 +455,10 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
         else           { desc = rd; push<SPILL>(st, ld, l_t, ct); }  // ties go right (Q10)
       } else if (l_hit) { desc = ld; }
       else if (r_hit)   { desc = rd; }
-      else walking = pop_closer<SPILL>(st, tmin, desc);
+      else desc = pop_closer<SPILL>(st, tmin);
     }
     // ---- leaf: bvh.cpp:241-252, then the pop loop ----
-    if (walking) {
+    if (desc != kDescDone) {
       const uint32_t index = desc_index(desc), n = desc_count(desc);
       for (uint32_t s = index; s < index + n; ++s) {
         const Geom g = load_geom(sc.bgeom, s);
@@ -466,7 +469,7 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
           hit_geom = g;
         }
       }
-      walking = pop_closer<SPILL>(st, tmin, desc);
+      desc = pop_closer<SPILL>(st, tmin);
     }
   }
   if (hit >= 0) hit_point = ray.d * tmin + ray.o;
@@ -483,19 +486,19 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
   const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
   if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, false)) return false;
-  uint32_t desc = __float_as_uint(root.lo.w);
-  bool walking = true, occluded = false;
-  // bvh.cpp:329-338: pop all, continue from the first-pushed entry; false = nothing left
+  uint32_t desc = __float_as_uint(root.lo.w);  // or kDescDone, as in bvh_closest
+  bool occluded = false;
+  // bvh.cpp:329-338: pop all, continue from the first-pushed entry; nothing left = done
   auto restart_from_bottom = [&]() {
     if (st.sp > 0) {
       desc = stack_read<SPILL>(st, 0).x;
       st.sp = 0;
-      return true;
+    } else {
+      desc = kDescDone;
     }
-    return false;
   };
-  while (walking) {
-    while (walking && !(desc & kDescLeaf)) {
+  while (desc != kDescDone) {
+    while (!(desc & kDescLeaf)) {
       const uint32_t index = desc_index(desc);
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
       float l_t, r_t;
@@ -509,20 +512,20 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
         else           { desc = rd; push<SPILL>(st, ld, l_t, ct); }
       } else if (l_hit) { desc = ld; }
       else if (r_hit)   { desc = rd; }
-      else walking = restart_from_bottom();
+      else restart_from_bottom();
     }
-    if (walking) {
+    if (desc != kDescDone) {
       const uint32_t index = desc_index(desc), n = desc_count(desc);
       for (uint32_t s = index; s < index + n; ++s) {
         const Geom g = load_geom(sc.bgeom, s);
         float curr_t;
         if (intercepts(g, ray, curr_t, ct)) {  // entries stay behind (Q2)
           occluded = true;
-          walking = false;
           break;
         }
       }
-      if (walking) walking = restart_from_bottom();
+      if (occluded) desc = kDescDone;
+      else restart_from_bottom();
     }
   }
   return occluded;
