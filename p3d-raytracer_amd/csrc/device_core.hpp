@@ -515,14 +515,15 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
       else restart_from_bottom();
     }
     if (desc != kDescDone) {
-      const uint32_t index = desc_index(desc), n = desc_count(desc);
-      for (uint32_t s = index; s < index + n; ++s) {
+      uint32_t s = desc_index(desc);
+      const uint32_t end = s + desc_count(desc);
+      bool more = s < end;
+      while (more) {  // one loop condition, no exit from the middle (see pop_closer)
         const Geom g = load_geom(sc.bgeom, s);
         float curr_t;
-        if (intercepts(g, ray, curr_t, ct)) {  // entries stay behind (Q2)
-          occluded = true;
-          break;
-        }
+        occluded = intercepts(g, ray, curr_t, ct);  // a hit ends the query; its entries stay behind (Q2)
+        ++s;
+        more = !occluded && s < end;
       }
       if (occluded) desc = kDescDone;
       else restart_from_bottom();

@@ -136,6 +136,9 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
       uint32_t unit_first_sample = 0;
       uint32_t unit_ch0[kCh0Counters] = {0, 0, 0, 0, 0};
       F3 chain_result = f3(0, 0, 0);
+#ifdef P3D_PT_PROFILE
+      RegionProf prof; prof.init();  // (instrumented build: the level body marks its regions; only the megakernel reports them)
+#endif
 #include "whitted_level.inc"
       (void)n_deferred; (void)unit_first_sample;
       if (STATS && LIT == 1) {  // counters per unit, accumulated level by level (handoff.hpp: ucount)
