@@ -384,6 +384,7 @@ __device__ __forceinline__ F3 get_normal(const Geom& g, const float4* normals, F
 //   (inner) or first leaf slot (leaf).
 constexpr uint32_t kDescLeaf = 0x80000000u;
 constexpr uint32_t kDescDone = 0xffffffffu;  // traversal state "no node left"; never a descriptor (it would be a leaf of 7 objects at slot 2^28 - 1)
+constexpr uint32_t kDescHit = 0xfffffffeu;   // any-hit traversal state "a primitive was hit" (nor this: slot 2^28 - 2); both have the leaf bit
 __device__ __host__ __forceinline__ uint32_t desc_index(uint32_t d) { return d & 0x0fffffffu; }
 __device__ __host__ __forceinline__ uint32_t desc_count(uint32_t d) { return (d >> 28) & 7u; }
 
@@ -432,7 +433,7 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
   int hit = -1;
   const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
-  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, false)) return -1;  // stale entries stay (Q2)
+  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, !__any(ray.odd_inv))) return -1;  // stale entries stay (Q2)
   if (root_passed) *root_passed = true;
   // The traversal state is ONE word: the descriptor of the node the lane stands on, or kDescDone (leaf bit set, so
   // that a finished lane also falls out of the descend loop): fewer lane masks for the compiler to carry round the loops.
@@ -485,9 +486,9 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
   float tmp;
   const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
-  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, false)) return false;
-  uint32_t desc = __float_as_uint(root.lo.w);  // or kDescDone, as in bvh_closest
-  bool occluded = false;
+  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, !__any(ray.odd_inv))) return false;
+  // state word as in bvh_closest, with a second end state: kDescHit = a primitive was hit (no flag to carry round the loops)
+  uint32_t desc = __float_as_uint(root.lo.w);
   // bvh.cpp:329-338: pop all, continue from the first-pushed entry; nothing left = done
   auto restart_from_bottom = [&]() {
     if (st.sp > 0) {
@@ -497,7 +498,7 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
       desc = kDescDone;
     }
   };
-  while (desc != kDescDone) {
+  while (desc < kDescHit) {
     while (!(desc & kDescLeaf)) {
       const uint32_t index = desc_index(desc);
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
@@ -514,10 +515,10 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
       else if (r_hit)   { desc = rd; }
       else restart_from_bottom();
     }
-    if (desc != kDescDone) {
+    if (desc < kDescHit) {
       uint32_t s = desc_index(desc);
       const uint32_t end = s + desc_count(desc);
-      bool more = s < end;
+      bool occluded = false, more = s < end;
       while (more) {  // one loop condition, no exit from the middle (see pop_closer)
         const Geom g = load_geom(sc.bgeom, s);
         float curr_t;
@@ -525,11 +526,11 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
         ++s;
         more = !occluded && s < end;
       }
-      if (occluded) desc = kDescDone;
+      if (occluded) desc = kDescHit;
       else restart_from_bottom();
     }
   }
-  return occluded;
+  return desc == kDescHit;
 }
 
 // ---------------------------------------------------------------------------
