@@ -6,7 +6,13 @@
 
 s_memtime deltas, entries and active lanes per region of whitted_kernel's chain loop, summed over all waves.
 The mark behind the closest-hit query is taken by the first lanes that leave the traversal loop, so
-the second line is the time they then wait for the slowest lane of the wave (divergence)."""
+the second line is the time they then wait for the slowest lane of the wave (divergence).
+
+CAVEAT (round 2): do not read the split between traversal and shading off this tool.  Every mark is an
+`s_waitcnt 0` + `s_memtime`: outstanding stores (level records) are charged to whatever region comes next, and the
+compiler moves code across the marks.  On balls_low it reports 5 % for the shadow feelers' traversals; a build that
+answers the feelers without traversing runs in HALF the time (ablation builds).  Use it for
+entries / active lanes per region; for time, build an ablation variant and time the kernel."""
 import ctypes as C
 import os
 import sys
