@@ -479,19 +479,21 @@ def cpu_baseline(workload, scene_path, cfg, res):
     if workload in ("cfg1", "cfg2"):
         x0 = y0 = 0
         w = h = res
-        reps = 5
-        sample = "%d whole frames of the same workload (%dx%d), best of %d" % (reps, res, res, reps)
+        what = "whole frames of the same workload (%dx%d)" % (res, res)
     else:
         w = h = 256 if workload in ("tri100k", "cfg4", "cornell_pt") else (64 if workload == "cfg3" else 16)
         x0 = y0 = (res - w) // 2
-        reps = 2
-        sample = "centred %dx%d crop of the %dx%d frame, best of %d" % (w, h, res, res, reps)
+        what = "renders of the centred %dx%d crop of the %dx%d frame" % (w, h, res, res)
     sc.render(ocfg, x0, y0, 8, 8)  # builds the BVH outside the timed region
-    best, rays = None, 0
-    for _ in range(reps):
+    # bounded sample: repeat until about 10 s of CPU work are done (at least 2, at most 64 repetitions), keep the best
+    best, rays, reps, spent = None, 0, 0, 0.0
+    while reps < 2 or (spent < 10.0 and reps < 64):
         _, _, st = sc.render(ocfg, x0, y0, w, h)
+        reps += 1
+        spent += st.seconds
         if best is None or st.seconds < best:
             best, rays = st.seconds, st.rays
+    sample = "%d %s, %.1f s of CPU work, best one counted" % (reps, what, spent)
     out = {"value": round(rays / best / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample}
     # all cores of ONE socket (rows dealt round-robin over that many threads, pinned to the socket; per-pixel stack —
     # the reference's serial stack cannot be threaded), best of 3; informational
