@@ -355,6 +355,11 @@ class DeviceScene:
             return rgb, hit, rgb8, st
         return rgb, hit, st
 
+    def status(self):
+        """p3d_scene_status: waits for the device, returns P3D_OK (0) or the code of a device-detected error of the
+        asynchronous render_device calls since the last check (message: last_error())."""
+        return int(self._L.p3d_scene_status(self._h))
+
     def render_device(self, cfg, tile, d_rgb=0, d_hit=0, d_rgb8=0, stream=0, stats=None):
         """Device-buffer form: raw HBM addresses (e.g. torch.Tensor.data_ptr()) and a hipStream_t."""
         _check(self._L.p3d_render_tile_device(self._h, C.byref(cfg), C.byref(tile), C.c_void_p(d_rgb or None),

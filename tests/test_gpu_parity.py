@@ -782,6 +782,39 @@ def test_fuzz_random_scenes_path_tracer(seed, tmp_path):
         assert (st.rays_primary, st.rays_bounce, st.rays_light) == (o_st.rays_primary, o_st.rays_bounce, o_st.rays_light), (seed, accel)
 
 
+def test_frames_in_flight_on_several_scenes_render_the_same_bits():
+    """What bench.py's timed loop does on one GPU (INTEGRATION.md "several frames in flight"): consecutive frames go
+    round-robin to four device scenes on four HIP streams (the default stream + three others), nothing waits until the
+    end.  Every frame that comes out of that — literal hand-off with its dependent launches overlapping other frames'
+    pass 1, and the per-pixel stack — must be the frame one scene renders on its own, bit for bit; so must the
+    device-detected status of every scene."""
+    import torch
+    hs = p3d.HostScene(scene_path("balls_low.p3f"))
+    res = 256
+    hs.set_resolution(res, res)
+    n = res * res
+    for mode in (p3d.STACK_LITERAL, p3d.STACK_PER_PIXEL):
+        cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, stack_mode=mode)
+        alone = p3d.DeviceScene(hs, bvh=True)
+        rgb0, hit0, _ = alone.render(cfg)
+        nfl = 4
+        scenes = [p3d.DeviceScene(hs, bvh=True) for _ in range(nfl)]
+        streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nfl - 1)]
+        bufs = [torch.zeros(n * 16, dtype=torch.uint8, device="cuda") for _ in range(nfl)]
+        tile = scenes[0].full_tile()
+        for i in range(5 * nfl):  # the last round's frames are the ones compared; the earlier ones keep the chip busy
+            k = i % nfl
+            scenes[k].render_device(cfg, tile, d_rgb=bufs[k].data_ptr(), d_hit=bufs[k].data_ptr() + n * 12, stream=streams[k].cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(nfl):
+            assert scenes[k].status() == 0
+            host = bufs[k].cpu().numpy()
+            rgb = host[: n * 12].view(np.float32).reshape(res, res, 3)
+            hit = host[n * 12:].view(np.int32).reshape(res, res)
+            assert (hit == hit0).all(), (mode, k)
+            assert (rgb.view(np.uint32) == np.ascontiguousarray(rgb0).view(np.uint32)).all(), (mode, k)
+
+
 def test_bench_contract_json_line():
     """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline`.  The headline value is
     the LITERAL frame (bit-identical to the reference's order); the roofline is a bound (frac <= 1 whenever the PMC
