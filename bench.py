@@ -300,6 +300,16 @@ def main():
         render_into(bufs[0], tile, cfg, stats=p3d.Stats(), scene=sc_, on=st_)
     dt = timed_loop(cfg)
 
+    # what the timed frames left in their slots must be, bit for bit, the frame one scene renders on its own
+    flight_check = None
+    if nfl > 1:
+        frames = [(b[0].clone(), b[1].clone()) for b in flight_bufs[:min(nfl, args.steps)]]
+        render_into(bufs[1], tile, cfg)
+        torch.cuda.synchronize()
+        ok = all(torch.equal(f[0], bufs[1][0]) and torch.equal(f[1], bufs[1][1]) for f in frames)
+        ok = ok and all(sc_.status() == 0 for sc_, _ in flight)
+        flight_check = "ok" if ok else "MISMATCH"
+
     # Launch durations inside the frame, live: HIP events of the library on the launch stream (p3d_stats.kernel_ms /
     # pass1_ms / handoff_ms), 16 frames after the timed region, smallest and mean.
     probes = []
@@ -423,6 +433,7 @@ def main():
                        "outputs_per_rank": "float RGB + hit ID (16 B/px) + u8 image (3 B/px), all written to HBM",
                        "tile_order": args.tile_order,
                        "frames_in_flight": nfl,
+                       "frames_in_flight_check": ("each slot's last timed frame vs the frame one scene renders alone, all outputs: %s" % flight_check) if flight_check else None,
                        "parallelism": "image rows in %d-row stripes, round-robin over %d GPU(s)%s"
                                       % (stripe_h, world,
                                          "; every frame's %s gathered to rank 0 over %s, %d frame(s) per collective, "

@@ -834,7 +834,7 @@ def test_bench_contract_json_line():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["vs_baseline"] is None
     assert d["config"]["rays_per_frame"] == 4944908 and "workload" in d["config"] and "model" not in d["config"]
-    assert d["config"]["stack_mode"] == "literal" and d["frame"]["handoff"]["redone"] == 9995 and d["config"]["frames_in_flight"] == 4
+    assert d["config"]["stack_mode"] == "literal" and d["frame"]["handoff"]["redone"] == 9995 and d["config"]["frames_in_flight"] == 4 and d["config"]["frames_in_flight_check"].endswith(": ok")
     assert d["frame"]["cold_kernel_ms"] >= d["frame"]["kernel_ms"] * 0.9
     rf = d["roofline"]
     assert rf["bound"] == "valu_issue" and rf["unit"] == "Gwave-instr/s" and abs(rf["peak"] - 1228.8) < 1e-6
