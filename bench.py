@@ -16,8 +16,8 @@ Workloads
 
 `value` is measured with the default p3d_config.stack_mode = P3D_STACK_LITERAL, whose frames are bit-identical to
 the reference's serial pixel order (tests/test_gpu_parity.py); `per_pixel_stack` is the same frame with the stack
-emptied at every primary sample (one launch, <= 1e-4 from the reference on sphere scenes, identical on triangle
-scenes).  Rays are counted as the reference's frame has them (one traversal query each).
+emptied at every primary sample (one launch, <= 1e-4 from the reference on sphere scenes, identical on the
+100k-triangle scene).  Rays are counted as the reference's frame has them (one traversal query each).
 
 On one GPU the timed loop keeps four frames in flight (--frames-in-flight 4): frame i is rendered by device scene i % 4 on
 stream i % 4 into buffers of its own — the caller-side way to overlap the latency-bound parts of a frame (its slowest
