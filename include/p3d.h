@@ -354,14 +354,19 @@ int p3d_render_tile_device(p3d_scene* scene, const p3d_config* cfg, const p3d_ti
                            void* hip_stream, p3d_stats* stats);
 
 /*
- * Errors a kernel detects while it runs (a hit_stack leftover that outgrew its record, a sample hand-out loop that
- * reached its trip bound and would write pixels with samples missing) raise a flag on the device.  The host-buffer
+ * Errors a kernel detects while it runs (a hit_stack leftover that outgrew its record, a work list of the hit_stack
+ * hand-off that overflowed or did not run empty within its round bound, a row of a stripe or sub-rectangle whose
+ * incoming hit_stack could not be established, a sample hand-out loop that reached its trip bound and would write pixels
+ * with samples missing) raise a flag on the device.  The host-buffer
  * call and every call with `stats` turn it into P3D_ERR_CAPACITY themselves; after device-buffer calls without
  * `stats` ask here: waits for the scene's device, returns P3D_OK or P3D_ERR_CAPACITY and clears the flag.
  */
 int p3d_scene_status(p3d_scene* scene);
 /* Test hook: trip bound of the four-lanes-per-pixel sample loops (0 = the real bound), process-wide. */
 int p3d_debug_set_trip_bound(uint32_t trips);
+/* Test hook: round bound of the hit_stack hand-off (0 = the real bound, min(units + 2, 4096)), process-wide.  A work
+ * list that is not empty after that many rounds makes the call fail: the frame would not be the serial one. */
+int p3d_debug_set_max_rounds(uint32_t rounds);
 
 /*
  * Batched traversal queries — device counterparts of BVH::intersect_bvh

@@ -223,48 +223,108 @@ struct DevScene {
 };
 
 // Per-lane traversal stack (bvh.cpp:86 hit_stack, one per pixel instead of one per process:
-// see DESIGN.md "Sequential state").  The first `cap` entries live in LDS; deeper entries
-// (rare: the worst case is (lights+1)*(tree depth-1), typical depth is a handful) spill to
-// a per-thread column of a global scratch array, so no launch ever has to be repeated.
+// see DESIGN.md "Sequential state").
+//   SPILL == false: the host guarantees that the worst-case height fits the LDS part; every access is a plain
+//                   ds_read_b64 / ds_write_b64 at  base[e * kBlock].
+//   SPILL == true : LDS holds a WINDOW of the `cap` (a power of two) most recent entries, entry e in slot e & (cap - 1);
+//                   entries [lo, sp) are in the window, entries [0, lo) in a per-thread column of a global backing
+//                   array.  A push into a full window moves the window's oldest entry out (it sits in the very slot the
+//                   new entry takes); a pop below the window reads the backing array.  The traversals work at the top of the
+//                   stack, so the backing array is only touched by what sinks out of the window and comes back: the stale
+//                   leftovers of earlier any-hit queries (Q2) under a deep closest-hit traversal.  (Until round 3 the LDS
+//                   part held the FIRST cap entries: under a leftover of a dozen entries every push and pop of the next
+//                   query went to global memory; 100k triangles 2048x2048: 1.7 GB written per frame, profiles/r03.)
 typedef __attribute__((address_space(3))) unsigned long long lds_uint2;  // explicit LDS pointer to one 8-byte entry: ds_read/write_b64, never flat_*
 struct Stack {
-  lds_uint2* base;  // LDS: &stack[lane]; entry e at base[e * kBlock]
-  uint2* spill;     // global: &spill[thread]; entry cap+e at spill[e * spill_stride]
-  uint32_t spill_stride;
+  lds_uint2* base;  // LDS: &stack[lane]; slot s at base[s * kBlock]
+  uint2* spill;     // global backing array (wave-uniform base: scalar registers); entry e of this thread at spill[e * spill_stride + tid]
+  uint32_t spill_stride, tid;  // (a 32-bit element offset from a uniform base costs one address register, a per-lane pointer two)
   int sp;
-  int cap;
+  int lo;           // SPILL only: first entry held in the LDS window
+  int cap;          // LDS entries per lane (SPILL: a power of two)
 };
 __device__ __forceinline__ lds_uint2* lds_stack_ptr(float4* smem_base, size_t float4_offset, uint32_t lane) {
   return (lds_uint2*)(reinterpret_cast<unsigned long long*>(smem_base + float4_offset)) + lane;
 }
-// SPILL == false: the host guarantees cap >= worst-case height, every access is a plain
-// ds_read_b64 / ds_write_b64.  SPILL == true (deep trees): entries >= cap go to global memory.
+__device__ __forceinline__ void stack_clear(Stack& s) { s.sp = 0; s.lo = 0; }
+__device__ __forceinline__ uint2 unpack_entry(unsigned long long v) { return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
 template <bool SPILL, class CT>
 __device__ __forceinline__ void push(Stack& s, uint32_t node, float t, CT& ct) {
-  const uint2 e = make_uint2(node, __float_as_uint(t));
-  if (!SPILL || s.sp < s.cap) {
-    lds_uint2* p = s.base + s.sp * kBlock;
-    *p = (unsigned long long)e.x | ((unsigned long long)e.y << 32);
+  const unsigned long long e = (unsigned long long)node | ((unsigned long long)__float_as_uint(t) << 32);
+  if (!SPILL) {
+    *(s.base + s.sp * kBlock) = e;
   } else {
-    s.spill[(size_t)(s.sp - s.cap) * s.spill_stride] = e;
+    lds_uint2* p = s.base + (s.sp & (s.cap - 1)) * kBlock;
+    if (s.sp - s.lo == s.cap) {  // window full: its oldest entry lives in this slot and moves to the backing array
+      s.spill[(uint32_t)s.lo * s.spill_stride + s.tid] = unpack_entry(*p);
+      ++s.lo;
+#ifdef P3D_ABL_COUNT_SPILLS  // (ablation builds only: entries that left the window, counted in the box-test slot)
+      ct.add(kBoxTests);
+#endif
+    }
+    *p = e;
   }
   ++s.sp;
   ct.stack_depth(s.sp);
 }
+// entry i < sp, wherever it lives; the stack is not changed
 template <bool SPILL>
 __device__ __forceinline__ uint2 stack_read(const Stack& s, int i) {
   uint2 e;
-  if (!SPILL || i < s.cap) {
-    const lds_uint2* p = s.base + i * kBlock;
-    const unsigned long long v = *p;
-    e = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-    if (SPILL) asm volatile("" : "+v"(e.x), "+v"(e.y));  // keep the two address spaces apart (no flat_load)
+  if (!SPILL) {
+    e = unpack_entry(*(s.base + i * kBlock));
+  } else if (i >= s.lo) {
+    e = unpack_entry(*(s.base + (i & (s.cap - 1)) * kBlock));
+    asm volatile("" : "+v"(e.x), "+v"(e.y));  // keep the two address spaces apart (no flat_load)
   } else {
-    e = s.spill[(size_t)(i - s.cap) * s.spill_stride];
+    e = s.spill[(uint32_t)i * s.spill_stride + s.tid];
     asm volatile("" : "+v"(e.x), "+v"(e.y));
   }
   return e;
 }
+// --sp and the entry that was on top
+template <bool SPILL>
+__device__ __forceinline__ uint2 pop(Stack& s) {
+  --s.sp;
+  const uint2 e = stack_read<SPILL>(s, s.sp);
+  if (SPILL && s.sp < s.lo) s.lo = s.sp;  // popped below the window: the window is empty now
+  return e;
+}
+
+// Shading state of a Whitted level that is written once and read once or twice per level but would otherwise sit in
+// registers through every traversal of the level: the hit point (only a refraction needs it again) and the diffuse / specular
+// sums of the light loop.  ON: nine dwords per lane in LDS behind the node stack (ds_read / ds_write around the light loop's
+// bookkeeping) for the kernels that trade registers for waves (scenes traversed from L2: the register allocator spilled
+// these very values to scratch memory, 1.4 GB of HBM writes per 2048x2048 frame of 100k triangles, profiles/r03).
+// OFF: plain registers.
+typedef __attribute__((address_space(3))) float lds_float;
+template <bool ON>
+struct ColdState {
+  F3 pn_, diff_, spec_;
+  __device__ __forceinline__ void bind(float4*, size_t, uint32_t) {}
+  __device__ __forceinline__ void set_pn(F3 v) { pn_ = v; }
+  __device__ __forceinline__ F3 pn() const { return pn_; }
+  __device__ __forceinline__ void clear_sums() { diff_ = f3(0, 0, 0); spec_ = f3(0, 0, 0); }
+  __device__ __forceinline__ void add(F3 d, F3 s) { diff_ = diff_ + d; spec_ = spec_ + s; }
+  __device__ __forceinline__ F3 diff() const { return diff_; }
+  __device__ __forceinline__ F3 spec() const { return spec_; }
+};
+template <>
+struct ColdState<true> {
+  lds_float* p;  // &cold[0][lane]; dword k at p[k * kBlock]
+  __device__ __forceinline__ void bind(float4* smem_base, size_t float4_offset, uint32_t lane) {
+    p = (lds_float*)(reinterpret_cast<float*>(smem_base + float4_offset)) + lane;
+  }
+  __device__ __forceinline__ void put(int k, F3 v) { p[k * kBlock] = v.x; p[(k + 1) * kBlock] = v.y; p[(k + 2) * kBlock] = v.z; }
+  __device__ __forceinline__ F3 get(int k) const { return f3(p[k * kBlock], p[(k + 1) * kBlock], p[(k + 2) * kBlock]); }
+  __device__ __forceinline__ void set_pn(F3 v) { put(0, v); }
+  __device__ __forceinline__ F3 pn() const { return get(0); }
+  __device__ __forceinline__ void clear_sums() { put(3, f3(0, 0, 0)); put(6, f3(0, 0, 0)); }
+  __device__ __forceinline__ void add(F3 d, F3 s) { put(3, get(3) + d); put(6, get(6) + s); }
+  __device__ __forceinline__ F3 diff() const { return get(3); }
+  __device__ __forceinline__ F3 spec() const { return get(6); }
+};
+constexpr uint32_t kColdDwords = 9;
 
 struct Geom {
   float4 a, b, c;
@@ -413,8 +473,7 @@ __device__ __forceinline__ uint32_t pop_closer(Stack& st, float tmin) {
   uint32_t desc = kDescDone;
   bool more = st.sp > 0;
   while (more) {
-    --st.sp;
-    const uint2 e = stack_read<SPILL>(st, st.sp);
+    const uint2 e = pop<SPILL>(st);
     const bool take = __uint_as_float(e.y) < tmin;
     if (take) desc = e.x;
     more = !take && st.sp > 0;
@@ -493,7 +552,7 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
   auto restart_from_bottom = [&]() {
     if (st.sp > 0) {
       desc = stack_read<SPILL>(st, 0).x;
-      st.sp = 0;
+      stack_clear(st);
     } else {
       desc = kDescDone;
     }

@@ -32,7 +32,7 @@ constexpr uint32_t kHaloChain = 8;        // frame pixels rendered in front of a
 constexpr uint32_t kMetaTouched = 1u << 17;
 constexpr uint32_t kNoUnit = 0xffffffffu;
 
-enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoError, kHoListA, kHoListB, kHoListC, kHoListD, kHoNumCounters };
+enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoUnused, kHoListA, kHoListB, kHoListC, kHoListD, kHoNumCounters };
 constexpr uint32_t kHoErrLeftoverCap = 1u;   // a leftover had more entries than a slot holds
 constexpr uint32_t kHoErrNoFixedPoint = 2u;  // round bound reached
 constexpr uint32_t kHoErrTrips = 4u;         // sample hand-out loop hit its trip bound (SUB = 4 kernels)
@@ -46,7 +46,8 @@ struct Handoff {
   uint32_t cap;         // entries per leftover slot
   uint32_t persistent;  // list kernel: one workgroup, loop over rounds until the list stays empty
   uint32_t list_cap;
-  uint32_t max_rounds;
+  uint32_t max_rounds;  // rounds (work-list launches + trips of the persistent workgroup) after which a non-empty list is an error
+  uint32_t round_base;  // rounds that came before this launch
   uint32_t count;       // keep the checked / redone statistics (one contended atomic per wave: only on request)
   uint32_t lanes;       // list kernel: list entries per wave (fewer = less divergence between unrelated pixels)
   uint2* entries;          // [2][cap][n_units]  leftover stacks, two slots per unit
@@ -127,10 +128,12 @@ __host__ __device__ inline int handoff_succ(const Handoff& H, uint32_t u) {
 
 __device__ __forceinline__ bool handoff_touched(const Handoff& H, uint32_t u) { return (H.touched[u >> 5] >> (u & 31u)) & 1u; }
 
-__device__ __forceinline__ void handoff_append(uint4* list, uint32_t* n, uint32_t cap, uint32_t* counters, uint4 e) {
+// `status`: the scene's error word (never cleared by a kernel; p3d_scene_status and every call with `stats` read it), so
+// that an overflow is not lost on a caller that renders into device buffers without asking for statistics.
+__device__ __forceinline__ void handoff_append(uint4* list, uint32_t* n, uint32_t cap, uint32_t* status, uint4 e) {
   const uint32_t i = atomicAdd(n, 1u);
   if (i < cap) list[i] = e;
-  else atomicOr(&counters[kHoError], kHoErrList);
+  else atomicOr(status, kHoErrList);
 }
 
 }  // namespace p3d

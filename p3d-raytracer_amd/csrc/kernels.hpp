@@ -97,8 +97,8 @@ struct RenderParams {
   float4* levels;          // Whitted per-level records {local colour, child weight}, [level][thread]
   uint32_t level_stride;   // threads in this launch
   unsigned long long* stats;  // kNumStats counters
-  uint2* spill;               // node-stack overflow area, [entry - stack_cap][thread]
-  int32_t stack_cap;          // node-stack entries per lane held in LDS
+  uint2* spill;               // backing array of the node stack (entries that sank out of the LDS window), [entry][thread]
+  int32_t stack_cap;          // node-stack entries per lane held in LDS (spilling stack: the window, a power of two)
   uint32_t lds_scene_f4;      // float4s reserved for the staged scene (0 when not staged)
   // Cost-ordered tile schedule (DESIGN.md "Tile schedule"); both null: frame order, nothing recorded.
   //   sched: see sched_build_kernel.   tile_cost[t]: wall-clock ticks the workgroup of tile t was resident.
@@ -346,7 +346,7 @@ __device__ __forceinline__ bool halo_unit_of_lane(const RenderParams& P, uint32_
 
 template <bool SPILL, class CT>
 __device__ __forceinline__ void seed_stack(Stack& st, const Handoff& H, uint32_t pred, uint32_t slot_count, CT& ct) {
-  st.sp = 0;
+  stack_clear(st);
   const uint32_t n = slot_count & 0xffffu, slot = slot_count >> 16;
   for (uint32_t e = 0; e < n; ++e) {
     const uint2 v = H.entries[((size_t)slot * H.cap + e) * H.n_units + pred];
@@ -452,11 +452,16 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
   st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
-  st.spill = P.spill + (blockIdx.x * kBlock + lane);
+  st.spill = P.spill;
+  st.tid = blockIdx.x * kBlock + lane;
   st.spill_stride = P.level_stride;
-  st.sp = 0;
+  stack_clear(st);
   st.cap = P.stack_cap;
   const uint32_t gid = blockIdx.x * kBlock + lane;
+  // cold shading state behind the node stack (device_core.hpp ColdState): only the kernels that trade registers for waves
+  constexpr bool COLD = !LDS && !AA;
+  ColdState<COLD> cold;
+  cold.bind(smem, P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2, lane);
   // per-pixel sample hand-out state behind the node stack (only allocated for SUB == 4); explicit LDS address space
   LdsPtPixelShared& shared = *(LdsPtPixelShared*)(smem + P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2);
   if (SUB == 4 && sub == 0) {
@@ -478,8 +483,8 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
       n_in = __hip_atomic_load(n_in_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       n_in = n_in > H.list_cap ? H.list_cap : n_in;
       if (n_in == 0) break;
-      if (H.persistent && round >= H.max_rounds) {
-        if (lane == 0) atomicOr(&H.counters[kHoError], kHoErrNoFixedPoint);
+      if (H.round_base + round >= H.max_rounds) {  // work left after the last round allowed: the frame is not the serial one
+        if (lane == 0) atomicOr(P.status, kHoErrNoFixedPoint);
         break;
       }
       if (H.count && blockIdx.x == 0 && lane == 0) atomicAdd(&H.counters[kHoRounds], 1u);
@@ -537,7 +542,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
         }
         if (active && H.count) atomicAdd(&H.counters[kHoRedone], 1u);
       }
-      if (LIT == 1) st.sp = 0;
+      if (LIT == 1) stack_clear(st);
 
       if (active) {
         const int c = up.c, r = up.r, x = up.x, y = up.y;
@@ -551,6 +556,14 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
 #ifdef P3D_PT_PROFILE
         RegionProf prof; prof.init();
 #endif
+        // one sample per pixel: the hit ID goes to memory when it is known instead of riding through the whole chain in a register
+        constexpr bool EARLY_HIT = !AA;
+        if (EARLY_HIT && P.hit_id && !(LIT != 0 && up.halo)) P.hit_id[(size_t)r * P.w + c] = -1;  // a primary ray that is never traced (none: every sample is) would leave -1
+#define P3D_FIRST_HIT(obj)                                                                                   \
+  do {                                                                                                       \
+    if (EARLY_HIT) { if (P.hit_id && !(LIT != 0 && up.halo)) P.hit_id[(size_t)r * P.w + c] = (obj); }        \
+    else first_hit = (obj);                                                                                  \
+  } while (0)
         if (SUB == 1) {
           for (int si = 0; si < SPP; ++si) {
             for (int sj = 0; sj < SPP; ++sj) {
@@ -611,6 +624,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
             first_hit = shared.first_hit[px];
           }
         }
+#undef P3D_FIRST_HIT
         if (AA) color = color / (float)(SPP * SPP);  // main.cpp:800
 #ifdef P3D_PT_PROFILE
         PT_REGION(8)
@@ -622,7 +636,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
           if (P.rgb) {
             P.rgb[3 * k] = color.x; P.rgb[3 * k + 1] = color.y; P.rgb[3 * k + 2] = color.z;
           }
-          if (P.hit_id) P.hit_id[k] = first_hit;
+          if (!EARLY_HIT && P.hit_id) P.hit_id[k] = first_hit;
           if (P.rgb8) {  // main.cpp:814-820
             F3 gc = color;
             if (P.gamma != 1.0f) {
@@ -666,7 +680,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
             for (uint32_t e = 0; e < n; ++e) H.entries[((size_t)nb * H.cap + e) * H.n_units + unit] = stack_read<SPILL>(st, (int)e);
             H.meta[unit] = n | (nb << 16) | kMetaTouched;
             const int succ = handoff_succ(H, unit);
-            if (succ >= 0) handoff_append(list_out, n_out_p, H.list_cap, H.counters, make_uint4((uint32_t)succ, unit, (nb << 16) | n, 1u));
+            if (succ >= 0) handoff_append(list_out, n_out_p, H.list_cap, P.status, make_uint4((uint32_t)succ, unit, (nb << 16) | n, 1u));
           }
         }
       }
@@ -798,9 +812,10 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
   ct.clear();
   Stack st;
   st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
-  st.spill = P.spill + (blockIdx.x * kBlock + lane);
+  st.spill = P.spill;
+  st.tid = blockIdx.x * kBlock + lane;
   st.spill_stride = P.level_stride;
-  st.sp = 0;
+  stack_clear(st);
   st.cap = P.stack_cap;
   const UnitPlace up = place_of_unit(P, unit);
   const uint32_t slot_count = pm & 0x1ffffu;
@@ -808,7 +823,7 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
   if (H.count) atomicAdd(&H.counters[kHoChecked], 1u);
   const float4 now = first_closest_hit<SPILL>(P, sc, st, up.x, up.y, P.antialiasing ? H.first_sample[unit] : 0u, ct);
   if (!same_first(now, H.first[unit]))
-    handoff_append(H.list_out, H.n_out, H.list_cap, H.counters, make_uint4(unit, (uint32_t)pred, slot_count, 0u));
+    handoff_append(H.list_out, H.n_out, H.list_cap, P.status, make_uint4(unit, (uint32_t)pred, slot_count, 0u));
   else
     replace_ch0_counters<STATS>(H, unit, ct, P.stats);
 }
@@ -836,9 +851,10 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   Stack st;
   st.base = lds_stack_ptr(smem, 0, threadIdx.x);
-  st.spill = P.spill + i;
+  st.spill = P.spill;
+  st.tid = i;
   st.spill_stride = P.spill_stride;
-  st.sp = 0;
+  stack_clear(st);
   st.cap = P.stack_cap;
   if (i >= P.n) return;
   Counters<false> ct;

@@ -40,7 +40,7 @@ constexpr uint32_t kLdsSceneLimitBytes = 26 * 1024;  // stage the scene in LDS u
 // A frame is rendered by as few launches as the per-thread scratch (level records + stack spill)
 // allows: every launch ends with a tail of partly idle CUs (2048x2048, 100k triangles: 30.3 ms in
 // two launches, 28.1 ms in one).
-constexpr size_t kLaunchScratchBudget = (size_t)2 << 30;
+constexpr size_t kLaunchScratchBudget = (size_t)4 << 30;
 constexpr uint32_t kMaxLaunchThreads = 1u << 24;
 
 inline F3 to_f3(const float v[3]) { return F3{v[0], v[1], v[2]}; }
@@ -99,6 +99,7 @@ inline uint32_t redo_lanes() {
   return v;
 }
 uint32_t g_debug_trip_bound = 0;  // tests: force the sample hand-out loops of the SUB = 4 kernels to give up early
+uint32_t g_debug_max_rounds = 0;  // tests: round bound of the hit_stack hand-off (0 = the real one)
 constexpr size_t kSchedCacheEntries = 16;
 constexpr uint32_t kSchedMinTiles = 8192;  // with fewer tiles than ~2 per wave slot nearly all start at once anyway
 
@@ -233,14 +234,64 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
   // every early return below frees what was allocated so far (device memory, events)
   auto s = std::unique_ptr<p3d_scene, void (*)(p3d_scene*)>(new p3d_scene(), &p3d_scene_destroy);
   s->device = device;
+  // ---- node records: relabelled, never reordered as far as a ray can tell ----
+  // A traversal only ever follows descriptors, so where a record lies is free; what the reference's order fixes is
+  // which child is visited first, and that is untouched.  Layout: one 32-byte pad, the root, then the CHILD PAIRS (64 B,
+  // 64-byte aligned: one visit = one half line; in the reference's numbering a pair starts at an odd node index,
+  // i.e. it straddled two 64-byte sectors, every second one two 128-byte lines).  Pairs are laid out two to a 128-byte
+  // line as "dominoes": a pair and the child pair of its bigger (by box area: likelier) child share a line, so that
+  // about every second step down the tree stays in the line it is in; the root shares its line with its own child pair.
+  // Pairs without a child pair (both children leaves: half of all pairs) follow behind, two to a line.
+  blob.push_back(make_float4(0, 0, 0, 0));
+  blob.push_back(make_float4(0, 0, 0, 0));
   s->off_nodes = (uint32_t)blob.size();
-  for (uint32_t i = 0; i < d->n_bvh_nodes; ++i) {
-    const p3d_bvh_node& n = d->bvh_nodes[i];
-    const uint32_t desc = (n.count_leaf & P3D_BVH_LEAF) ? (kDescLeaf | ((n.count_leaf & 7u) << 28) | n.index) : n.index;
-    float descf;
-    std::memcpy(&descf, &desc, 4);
-    blob.push_back(make_float4(n.bmin[0], n.bmin[1], n.bmin[2], descf));
-    blob.push_back(make_float4(n.bmax[0], n.bmax[1], n.bmax[2], 0.f));
+  uint32_t n_nodes_out = 0;
+  if (d->n_bvh_nodes) {
+    const p3d_bvh_node* N = d->bvh_nodes;
+    auto inner = [&](uint32_t i) { return !(N[i].count_leaf & P3D_BVH_LEAF); };
+    auto area = [&](uint32_t i) {
+      const double x = (double)N[i].bmax[0] - N[i].bmin[0], y = (double)N[i].bmax[1] - N[i].bmin[1], z = (double)N[i].bmax[2] - N[i].bmin[2];
+      const double a = x * y + y * z + z * x;
+      return a == a ? a : 0.0;
+    };
+    std::vector<uint32_t> slot_of(d->n_bvh_nodes, 0xffffffffu);  // inner node -> slot of its child pair
+    std::vector<uint32_t> singles, heads;
+    uint32_t next_slot = 0;
+    if (inner(0)) {
+      slot_of[0] = next_slot++;
+      for (int k = 1; k >= 0; --k) if (inner(N[0].index + k)) heads.push_back(N[0].index + k);  // left subtree first
+    }
+    while (!heads.empty()) {
+      const uint32_t h = heads.back();
+      heads.pop_back();
+      const uint32_t l = N[h].index, r = l + 1;
+      const bool li = inner(l), ri = inner(r);
+      if (!li && !ri) { singles.push_back(h); continue; }
+      const uint32_t second = (li && ri) ? (area(r) > area(l) ? r : l) : (li ? l : r);
+      slot_of[h] = next_slot++;       // an odd slot: the first half of a line
+      slot_of[second] = next_slot++;  // ... and the pair most rays take next in its second half
+      for (int k = 1; k >= 0; --k) if (inner(N[second].index + k)) heads.push_back(N[second].index + k);
+      const uint32_t other = second == l ? r : l;
+      if (inner(other)) heads.push_back(other);
+    }
+    for (uint32_t h : singles) slot_of[h] = next_slot++;
+    n_nodes_out = 1 + 2 * next_slot;
+    if (n_nodes_out > 0x0fffffffu) return fail(P3D_ERR_CAPACITY, "p3d_scene_create: BVH index exceeds 2^28");
+    blob.resize(blob.size() + (size_t)2 * n_nodes_out, make_float4(0, 0, 0, 0));
+    auto put = [&](uint32_t at, uint32_t old) {
+      const p3d_bvh_node& n = N[old];
+      const uint32_t desc = inner(old) ? 1u + 2u * slot_of[old] : (kDescLeaf | ((n.count_leaf & 7u) << 28) | n.index);
+      float descf;
+      std::memcpy(&descf, &desc, 4);
+      blob[s->off_nodes + 2 * (size_t)at] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], descf);
+      blob[s->off_nodes + 2 * (size_t)at + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], 0.f);
+    };
+    put(0, 0);
+    for (uint32_t i = 0; i < d->n_bvh_nodes; ++i)
+      if (slot_of[i] != 0xffffffffu) {  // (records no descriptor leads to are not uploaded)
+        put(1 + 2 * slot_of[i], N[i].index);
+        put(2 + 2 * slot_of[i], N[i].index + 1);
+      }
   }
   blob.resize(blob.size() + (size_t)2 * lbvh_nodes, make_float4(0, 0, 0, 0));  // filled in by lbvh::build
   s->off_bgeom = (uint32_t)blob.size();
@@ -295,7 +346,7 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
   v.mats = s->d_blob + s->off_mats;
   v.lights = s->d_blob + s->off_lights;
   v.emitters = s->d_emitters;
-  v.n_nodes = d->n_bvh_nodes;
+  v.n_nodes = n_nodes_out;
   v.n_slots = d->n_bvh_prim_index;
   v.n_objs = d->n_prims;
   v.n_mats = d->n_materials;
@@ -540,7 +591,7 @@ int check_status(p3d_scene* s) {
   if (h & kHoErrTrips) what += " sample hand-out loop reached its trip bound (pixels would miss samples);";
   if (h & kHoErrLeftoverCap) what += " a hit_stack leftover outgrew its slot;";
   if (h & kHoErrNoFixedPoint) what += " hit_stack hand-off did not reach a fixed point;";
-  if (h & kHoErrList) what += " a ray queue segment of the per-level launches overflowed;";
+  if (h & kHoErrList) what += " a work list of the hit_stack hand-off or a ray queue segment of the per-level launches overflowed;";
   return fail(P3D_ERR_CAPACITY, "device-detected error:" + what);
 }
 
@@ -570,7 +621,6 @@ int finish_stats(p3d_scene* s, hipStream_t st, p3d_stats* stats, bool literal) {
     uint32_t c[kHoNumCounters];
     P3D_HIP(hipMemcpy(c, s->ho_counters.p, sizeof(c), hipMemcpyDeviceToHost));
     stats->handoff_checked = c[kHoChecked]; stats->handoff_redone = c[kHoRedone]; stats->handoff_rounds = c[kHoRounds];
-    if (c[kHoError]) return fail(P3D_ERR_CAPACITY, "hit_stack hand-off: work list overflow");
   }
   return check_status(s);
 }
@@ -622,12 +672,17 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // 96 / 128 random objects 0.49 -> 0.42 / 0.75 -> 0.66 ms against traversing those 14-25 KB from L2.
   const bool lds_scene = (size_t)s->blob_f4 * sizeof(float4) <= (pt ? kLdsSceneLimitBytesPt : kLdsSceneLimitBytes) && (bound <= 24 || !pt);
   const bool lds_spill = lds_scene && !pt && (bound > 24 || (size_t)s->blob_f4 * sizeof(float4) + (size_t)bound * kBlock * sizeof(uint2) > 20 * 1024);
-  // LDS part of the node stack of a scene traversed from L2: at most 12 entries (6 KB per wave), so that the 24
-  // waves per CU the registers of the no-AA kernel allow also fit its 160 KB of LDS; deeper entries spill to global
-  // memory.  (24 entries = 13 waves per CU: 100k triangles 1024x1024 9.94 ms; 16 entries 8.43 ms at 4 waves per SIMD.)
-  const uint32_t depth_cap = std::min<uint32_t>(std::max<uint32_t>(s->bvh_max_depth + 3, 8), 12);
-  const uint32_t cap = cfg->accel == P3D_ACCEL_BVH ? ((lds_scene && !lds_spill) ? bound : std::min(bound, depth_cap)) : 1;
-  const uint32_t spill_entries = bound > cap ? bound - cap : 0;
+  // Spilling stack (scenes traversed from L2; LDS-staged scenes whose worst case does not fit): LDS holds a window of the
+  // most recent `window` entries (a power of two, device_core.hpp "Stack"), older entries sink into a per-thread column of
+  // a global backing array.  8 entries = 4 KB per wave: all 32 wave slots of a CU fit its 160 KB of LDS.
+  uint32_t window = 8;
+  if (const char* e = getenv("P3D_LDS_STACK_ENTRIES")) {  // experiments: LDS entries per lane (rounded up to a power of two)
+    window = 1;
+    while (window < (uint32_t)std::max(1, atoi(e)) && window < 1024) window *= 2;
+  }
+  const bool spilling = cfg->accel == P3D_ACCEL_BVH && !(lds_scene && !lds_spill);
+  const uint32_t cap = cfg->accel == P3D_ACCEL_BVH ? (spilling ? window : bound) : 1;
+  const uint32_t spill_entries = (spilling && bound > cap) ? bound : 0;  // rows of the backing array (entry e in row e)
   const bool want_counts = stats && cfg->collect_stats;
 
   RenderParams P{};
@@ -652,8 +707,11 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   const bool sub4 = (pt && cfg->spp_sqrt >= kPtSub4MinSppSqrt) ||
                     (!pt && !literal && !lds_scene && cfg->antialiasing && cfg->spp_sqrt >= kWhittedSub4MinSppSqrt);
   const uint32_t tp = sub4 ? 4 : 8;  // tile edge in pixels
+  // ... and behind the node stack: the sample ring of the four-lanes-per-pixel kernels, or the cold shading state of the
+  // Whitted kernels that traverse the scene from L2 without anti-aliasing (ColdState<true>, device_core.hpp)
+  const bool cold_lds = !pt && !lds_scene && !cfg->antialiasing;
   const size_t lds_bytes = (size_t)P.lds_scene_f4 * sizeof(float4) + (size_t)cap * kBlock * sizeof(uint2) +
-                           (sub4 ? sizeof(PtPixelShared) : 0);
+                           (sub4 ? sizeof(PtPixelShared) : 0) + (cold_lds ? (size_t)kColdDwords * kBlock * sizeof(float) : 0);
 
   // rows per launch: whole 8-row tile bands, at most kMaxLaunchThreads threads
   const uint32_t tiles_x = ((uint32_t)tile->w + tp - 1) / tp;
@@ -697,7 +755,10 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   const uint32_t halo_blocks_max = literal ? ((uint32_t)tile->h * kHaloChain + kBlock - 1) / kBlock : 0;
   const uint32_t max_threads = (blocks_for(tiles_x * bands_per_launch) + halo_blocks_max) * kBlock;
   const size_t tile_units = (size_t)tile->h * ((size_t)tile->w + kHaloChain);  // upper bound of H.n_units
-  if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * (per_level ? tile_units : (size_t)max_threads) * sizeof(float4)))) return rc;
+  // per-level launches keep one record per (level, unit); the work-list launches of a LITERAL frame behind them are the
+  // megakernel and index [level][launch thread] with up to max_threads threads, whatever the size of the tile
+  const size_t level_cols = per_level ? std::max<size_t>(tile_units, literal ? (size_t)max_threads : 0) : (size_t)max_threads;
+  if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * level_cols * sizeof(float4)))) return rc;
   if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)spill_entries * max_threads * sizeof(uint2)))) return rc;
   if (int rc = s->deferred.ensure(std::max<size_t>(16, (size_t)deferred * max_threads * sizeof(float4)))) return rc;
   P.levels = (float4*)s->levels.p;
@@ -779,6 +840,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     H.list_cap = H.n_units;
     H.count = want_counts ? 1u : 0u;
     H.max_rounds = std::min<uint32_t>(H.n_units + 2, 4096);  // a chain of n units is exact after n rounds at the latest; measured: 2.  Beyond the cap: P3D_ERR_CAPACITY
+    if (g_debug_max_rounds) H.max_rounds = g_debug_max_rounds;
     for (int i = 0; i < 4; ++i) ho_list[i] = (uint4*)s->ho_lists.p + (size_t)i * H.n_units;
     ho_counters = (uint32_t*)s->ho_counters.p;
     H.counters = ho_counters;
@@ -912,6 +974,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       H.list_in = ho_list[round]; H.n_in = ho_counters + kHoListA + round;
       H.list_out = ho_list[round + 1]; H.n_out = ho_counters + kHoListA + round + 1;
       H.persistent = round == 2 ? 1u : 0u;
+      H.round_base = (uint32_t)round;
       // round 0 renders unrelated deep pixels again; entries per wave: see P3D_REDO_LANES above
       H.lanes = round == 0 ? redo_lanes() : kBlock;
       const uint32_t blocks = round == 2 ? 1u : wide;
@@ -938,6 +1001,10 @@ int p3d_scene_status(p3d_scene* s) {
 
 int p3d_debug_set_trip_bound(uint32_t trips) {
   g_debug_trip_bound = trips;
+  return P3D_OK;
+}
+int p3d_debug_set_max_rounds(uint32_t rounds) {
+  g_debug_max_rounds = rounds;
   return P3D_OK;
 }
 
@@ -980,9 +1047,11 @@ static int trace_common(p3d_scene* s, uint32_t accel, uint32_t n, const float* o
   P3D_HIP(hipMemcpy(d_o, origin, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
   P3D_HIP(hipMemcpy(d_d, direction, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice));
   const uint32_t bound = accel == P3D_ACCEL_BVH ? std::max<uint32_t>(1, s->bvh_max_depth) : 1;
-  const uint32_t cap = std::min<uint32_t>(bound, 24);
+  const uint32_t cap = 16;  // LDS window of the spilling stack (a power of two), the rest in the backing array
   const uint32_t blocks = (n + kBlock - 1) / kBlock;
-  if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)(bound - cap) * blocks * kBlock * sizeof(uint2)))) return rc;
+  if ((uint64_t)(bound > cap ? bound : 0) * blocks * kBlock > 0xffffffffull)  // entries are addressed with 32-bit offsets (device_core.hpp Stack)
+    return fail(P3D_ERR_CAPACITY, "p3d_trace: too many rays for one call over a tree this deep (split the batch)");
+  if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)(bound > cap ? bound : 0) * blocks * kBlock * sizeof(uint2)))) return rc;
   TraceParams P{};
   P.sc = s->dev; P.n = n; P.origin = d_o; P.direction = d_d; P.hit_id = d_hit; P.hit_point = d_hp; P.occluded = d_occ;
   P.t = t_host ? d_t : nullptr; P.spill = (uint2*)s->spill.p; P.spill_stride = blocks * kBlock; P.stack_cap = (int32_t)cap;

@@ -83,9 +83,10 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
   st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
-  st.spill = P.spill + (blockIdx.x * kBlock + lane);
+  st.spill = P.spill;
+  st.tid = blockIdx.x * kBlock + lane;
   st.spill_stride = P.level_stride;
-  st.sp = 0;
+  stack_clear(st);
   st.cap = P.stack_cap;
   Pending pend;
   pend.base = P.levels + (blockIdx.x * kBlock + lane);
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
             break;
           }
           rng.seed_stream(P.seed, (uint32_t)(y * sc.cam.res_x + x), (uint32_t)s);
-          st.sp = 0;
+          stack_clear(st);
           F3 o, d;
           make_primary(P, sc.cam, x, y, si, sj, rng, o, d);
           ray_set(ray, o, d);

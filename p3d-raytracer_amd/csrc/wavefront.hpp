@@ -65,9 +65,10 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
   st.base = lds_stack_ptr(smem, 0, lane);
-  st.spill = P.spill + gid;
+  st.spill = P.spill;
+  st.tid = gid;
   st.spill_stride = P.level_stride;
-  st.sp = 0;
+  stack_clear(st);
   st.cap = P.stack_cap;
   const uint32_t seg = blockIdx.x & (kWfSegments - 1);
   uint32_t tx = 0, ty = 0;
@@ -109,7 +110,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
         ct.add(kRaysPrimary);
         if (!up.halo) ct.add(kPixels);
       }
-      st.sp = 0;
+      stack_clear(st);
     } else {
       if (chunk >= chunk_end) break;
       const uint32_t i = chunk * kBlock + lane;
@@ -136,10 +137,14 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
       uint32_t unit_first_sample = 0;
       uint32_t unit_ch0[kCh0Counters] = {0, 0, 0, 0, 0};
       F3 chain_result = f3(0, 0, 0);
+      constexpr bool COLD = false;
+      ColdState<COLD> cold;
 #ifdef P3D_PT_PROFILE
       RegionProf prof; prof.init();  // (instrumented build: the level body marks its regions; only the megakernel reports them)
 #endif
+#define P3D_FIRST_HIT(obj) first_hit = (obj)
 #include "whitted_level.inc"
+#undef P3D_FIRST_HIT
       (void)n_deferred; (void)unit_first_sample;
       if (STATS && LIT == 1) {  // counters per unit, accumulated level by level (handoff.hpp: ucount)
         if (up.halo) ct.clear();
@@ -160,9 +165,9 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
         const uint32_t at = atomicAdd(&P.wf_n_out[seg * kWfCounterStride], 1u);
         if (at < P.wf_seg_cap) {
           float4* q = P.wf_ray_out + ((size_t)seg * P.wf_seg_cap + at) * 2;
-          q[0] = make_float4(child.o.x, child.o.y, child.o.z, __uint_as_float(unit));
-          q[1] = make_float4(child.d.x, child.d.y, child.d.z, child_inside ? -child_ior : child_ior);
-          const uint32_t bin = ray_bin(P, child.o, child.d);
+          q[0] = make_float4(child_o.x, child_o.y, child_o.z, __uint_as_float(unit));
+          q[1] = make_float4(child_d.x, child_d.y, child_d.z, child_inside ? -child_ior : child_ior);
+          const uint32_t bin = ray_bin(P, child_o, child_d);
           P.wf_key_out[(size_t)seg * P.wf_seg_cap + at] = bin;
           atomicAdd(&P.wf_hist[bin], 1u);
         } else {

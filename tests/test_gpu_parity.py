@@ -422,6 +422,49 @@ def test_sample_loop_backstop_is_an_error_not_a_darker_pixel():
     assert (again.view(np.uint32) == good.view(np.uint32)).all()
 
 
+def test_hand_off_that_runs_out_of_rounds_is_an_error_also_without_stats():
+    """The hit_stack hand-off iterates its work lists to a fixed point; a list that is still not empty after the round
+    bound means the frame is not the serial one.  That must fail the call - also on the asynchronous path (device
+    buffers, no `stats`), where only p3d_scene_status can tell (forced here through the debug round bound: balls_low at
+    256x256 needs its second round)."""
+    import torch
+    dev, _ = _pair(scene_path("balls_low.p3f"), res=(256, 256), grid=False)
+    cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4)
+    good, _, st = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, collect_stats=1))
+    assert st.handoff_rounds >= 2
+    n = 256 * 256
+    buf = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
+    L = p3d.lib()
+    try:
+        L.p3d_debug_set_max_rounds(1)
+        with pytest.raises(p3d.P3DError) as e:
+            dev.render(cfg)
+        assert e.value.code == -4 and "fixed point" in str(e.value)
+        dev.render_device(cfg, dev.full_tile(), d_rgb=buf.data_ptr(), d_hit=buf.data_ptr() + n * 12)  # no stats: returns at once
+        assert dev.status() == -4 and "fixed point" in p3d.lib().p3d_last_error().decode()
+    finally:
+        L.p3d_debug_set_max_rounds(0)
+    assert dev.status() == 0  # read and cleared
+    again, _, _ = dev.render(cfg)
+    assert (again.view(np.uint32) == good.view(np.uint32)).all()
+
+
+def test_per_level_literal_small_tile_on_a_fresh_scene(tri5k_path):
+    """The work-list launches behind the per-level launches of a LITERAL frame are the megakernel and index their level
+    records by launch thread: on a tile of a few hundred pixels that is more columns than the tile has units.  A fresh
+    scene (nothing has grown the scratch yet), a 37x29 sub-rectangle: same bits as the megakernel's."""
+    hs = p3d.HostScene(tri5k_path)
+    hs.set_resolution(128, 128)
+    tile = p3d.Tile(40, 50, 37, 29, 0, 1)
+    frames = []
+    for chain in (p3d.CHAIN_PER_LEVEL, p3d.CHAIN_MEGAKERNEL):
+        dev = p3d.DeviceScene(hs, bvh=True)
+        rgb, hit, _ = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, chain_launch=chain), tile=tile)
+        assert dev.status() == 0
+        frames.append((rgb, hit))
+    assert (frames[0][0].view(np.uint32) == frames[1][0].view(np.uint32)).all() and (frames[0][1] == frames[1][1]).all()
+
+
 @pytest.mark.parametrize("n_objs", [0, 1, 2, 3])
 def test_device_built_bvh_tiny_scenes(n_objs, tmp_path):
     """Degenerate sizes of the GPU builder: no object (no tree), one (the root is a leaf), two and three."""
@@ -502,6 +545,62 @@ def test_full_size_tri100k_matches_reference_frame(tri100k_path):
         rgb, hit, st = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=6, collect_stats=1, stack_mode=mode))
         assert st.rays == 2887776
         assert hashlib.sha256(np.ascontiguousarray(rgb).tobytes()).hexdigest() == str(g["sha256"])
+
+
+def test_full_size_cfg4_2048_matches_the_oracle_fixture(tri100k_path):
+    """BASELINE configs[3] at its real size: 100k triangles, 2048x2048, Whitted depth 6, BVH.  The oracle needs a minute
+    for this frame in the reference's serial order, so its answer was recorded once (tests/golden/fullsize/cfg4.npz,
+    make_fullsize_fixtures.py): SHA-256 of the float frame and of the hit IDs, every 8th pixel, four crops, all
+    counters.  The literal frame must reproduce all of it, with the counting and with the timed instantiation; the
+    per-pixel stack gives the same picture here (triangles never re-normalise a ray) with its own test counts."""
+    import hashlib
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "fullsize", "cfg4.npz"))
+    want = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
+    hs = p3d.HostScene(tri100k_path)
+    hs.set_resolution(2048, 2048)
+    dev = p3d.DeviceScene(hs, bvh=True)
+    for mode in (p3d.STACK_LITERAL, p3d.STACK_PER_PIXEL):
+        for collect in (1, 0):
+            rgb, hit, st = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=6, collect_stats=collect, stack_mode=mode))
+            assert hashlib.sha256(np.ascontiguousarray(rgb).tobytes()).hexdigest() == str(g["sha256_rgb"])
+            assert hashlib.sha256(np.ascontiguousarray(hit).tobytes()).hexdigest() == str(g["sha256_hit"])
+            if collect and mode == p3d.STACK_LITERAL:
+                for k in COUNTERS:
+                    assert getattr(st, k) == want[k], k
+                assert st.max_stack >= int(g["max_stack"])
+            elif collect:
+                for k in ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "shaded_hits", "pixels"):
+                    assert getattr(st, k) == want[k], k
+    assert (rgb[::8, ::8].view(np.uint32) == g["sub8_rgb"].view(np.uint32)).all() and (hit[::8, ::8] == g["sub8_hit"]).all()
+    for (x0, y0), crop in zip(g["crop_xy"], g["crops"]):
+        assert (rgb[y0:y0 + 64, x0:x0 + 64].view(np.uint32) == crop.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
+def test_full_size_path_tracer_rows_match_the_oracle_fixture(name):
+    """BASELINE configs[2] (256 spp) and configs[4] (4096 spp through the thin lens) at 1024x1024: every 8th image row
+    at full width and full sampling (a tile with stripe_h = 1, stripe_stride = 8), against what the oracle rendered for
+    those rows in the build container (tests/golden/fullsize/<name>.npz: every 8th pixel of them, and the counters
+    summed over the rows).  Same paths on both sides: hit IDs and every counter equal, colours within 1e-4 of the HDR scale."""
+    from conftest import GOLDEN, ROOT
+    g = np.load(os.path.join(GOLDEN, "fullsize", name + ".npz"))
+    want = dict(zip([str(k) for k in g["counter_names"]], [int(v) for v in g["counters"]]))
+    rows = g["rows"]
+    assert (rows == np.arange(0, 1024, 8)).all()
+    lens = tuple(float(v) for v in g["lens"]) if float(g["lens"][0]) != 0 else None
+    hs = p3d.HostScene(os.path.join(ROOT, "scenes", "cornell.p3f"))
+    hs.set_resolution(1024, 1024)
+    if lens:
+        hs.set_lens(*lens)
+    dev = p3d.DeviceScene(hs, bvh=True)
+    cfg = p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=int(g["spp_sqrt"]), max_depth=20, dof=1 if lens else 0,
+                               seed=int(g["seed"]), collect_stats=1)
+    rgb, hit, st = dev.render(cfg, tile=p3d.Tile(0, 0, 1024, len(rows), 1, 8))
+    assert (hit[:, ::8] == g["sub8_hit"]).all()
+    assert np.abs(rgb[:, ::8] - g["sub8_rgb"]).max() <= TOL * max(1.0, float(np.abs(g["sub8_rgb"]).max()))
+    for k in ("rays_primary", "rays_bounce", "rays_light", "node_tests", "sphere_tests", "tri_tests", "shaded_hits", "pixels"):
+        assert getattr(st, k) == want[k], k
 
 
 @pytest.mark.parametrize("lens", [None, (10.0, 1.0)])
