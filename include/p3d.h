@@ -367,6 +367,9 @@ int p3d_debug_set_trip_bound(uint32_t trips);
 /* Test hook: round bound of the hit_stack hand-off (0 = the real bound, min(units + 2, 4096)), process-wide.  A work
  * list that is not empty after that many rounds makes the call fail: the frame would not be the serial one. */
 int p3d_debug_set_max_rounds(uint32_t rounds);
+/* Test hook: how many frame pixels the search in front of a row of a stripe / sub-rectangle may collect before it has to
+ * find one whose leftover provably does not depend on its own incoming hit_stack (0 = the real bound, 16), process-wide. */
+int p3d_debug_set_halo_chain(uint32_t pixels);
 
 /*
  * Batched traversal queries — device counterparts of BVH::intersect_bvh

@@ -31,7 +31,7 @@ LOAD_LEGACY_F11 = 1
 EXPORTS = [
     "p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_config_default",
     "p3d_scene_create", "p3d_scene_create_device_bvh", "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_render_tile", "p3d_render_tile_device",
-    "p3d_scene_status", "p3d_debug_set_trip_bound", "p3d_debug_set_max_rounds", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
+    "p3d_scene_status", "p3d_debug_set_trip_bound", "p3d_debug_set_max_rounds", "p3d_debug_set_halo_chain", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
     "p3d_trace_closest", "p3d_trace_any", "p3d_host_scene_load", "p3d_host_scene_destroy",
     "p3d_host_scene_set_resolution", "p3d_host_scene_set_lens", "p3d_host_scene_replicate_lights",
     "p3d_host_scene_desc", "p3d_host_scene_bind_device",
@@ -180,6 +180,7 @@ def lib():
         L.p3d_scene_status.argtypes = [C.c_void_p]
         L.p3d_debug_set_trip_bound.argtypes = [C.c_uint32]
         L.p3d_debug_set_max_rounds.argtypes = [C.c_uint32]
+        L.p3d_debug_set_halo_chain.argtypes = [C.c_uint32]
         _lib = L
     return _lib
 

@@ -485,9 +485,10 @@ __device__ __forceinline__ uint32_t pop_closer(Stack& st, float tmin) {
 // Returns the leaf slot of the hit (-1 = miss) and the hit point d*tmin + o (bvh.cpp:271).
 // *root_passed (optional): the ray got past the root test of bvh.cpp:203-205, i.e. the query touched hit_stack
 // and left it empty; a ray that fails it returns with the stack exactly as it found it.
+// *final_ray (optional): the private copy as the traversal leaves it (its direction re-normalised by the sphere tests it ran).
 template <bool SPILL, class CT>
 __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_point, Geom& hit_geom, CT& ct,
-                           bool* root_passed = nullptr, float* t_out = nullptr) {
+                           bool* root_passed = nullptr, float* t_out = nullptr, RayS* final_ray = nullptr) {
   float tmp, tmin = FLT_MAX;
   int hit = -1;
   const NodeRec root = load_node(sc.nodes, 0);
@@ -534,6 +535,7 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
   }
   if (hit >= 0) hit_point = ray.d * tmin + ray.o;
   if (t_out) *t_out = tmin;
+  if (final_ray) *final_ray = ray;
   return hit;
 }
 

@@ -28,7 +28,7 @@
 
 namespace p3d {
 
-constexpr uint32_t kHaloChain = 8;        // frame pixels rendered in front of a row that starts a chain of its own
+constexpr uint32_t kHaloChain = 16;       // slots in front of a row that starts a chain of its own: at most that many frame pixels are rendered for their leftovers
 constexpr uint32_t kMetaTouched = 1u << 17;
 constexpr uint32_t kNoUnit = 0xffffffffu;
 
@@ -37,6 +37,7 @@ constexpr uint32_t kHoErrLeftoverCap = 1u;   // a leftover had more entries than
 constexpr uint32_t kHoErrNoFixedPoint = 2u;  // round bound reached
 constexpr uint32_t kHoErrTrips = 4u;         // sample hand-out loop hit its trip bound (SUB = 4 kernels)
 constexpr uint32_t kHoErrList = 8u;          // a work list or a ray queue segment overflowed
+constexpr uint32_t kHoErrHalo = 16u;         // no pixel in front of a row could be shown to leave a stack that does not depend on what it found (halo_find_kernel)
 
 struct Handoff {
   uint32_t n_units;     // rows * row_units

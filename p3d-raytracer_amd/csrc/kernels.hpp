@@ -89,6 +89,7 @@ struct RenderParams {
   // tile
   int32_t x0, y0, w, h, stripe_h, stripe_stride;
   uint32_t tiles_x, tiles_y, xcd_chunk;
+  uint32_t tile_w_shift, tile_h_shift;  // one-lane-per-pixel kernels: a wave renders a (1 << w) x (1 << h) pixel tile: 8x8, 8x4 or 4x4 (host: tile_shape)
   // outputs (device memory, any may be null)
   float* rgb;
   int32_t* hit_id;
@@ -219,9 +220,12 @@ __global__ void __launch_bounds__(kSchedBuildThreads) sched_build_kernel(const u
 struct ClearParams {
   uint32_t* p[3];
   uint32_t n[3];
+  const uint32_t* halo_verdict;  // kHoErrHalo or 0 as the last halo_find_kernel launch for this tile left it (the search is
+  uint32_t* status;              // memoised per tile; its verdict holds for every frame that uses the memoised chain)
 };
 __global__ void __launch_bounds__(256) clear_kernel(const ClearParams C) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  if (i == 0 && C.halo_verdict && *C.halo_verdict) atomicOr(C.status, *C.halo_verdict);
   for (int k = 0; k < 3; ++k)
     for (uint32_t j = i; j < C.n[k]; j += stride) C.p[k][j] = 0;
 }
@@ -445,7 +449,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
   stage_scene<LDS>(sc, P, smem);
 
   const uint32_t lane = threadIdx.x;
-  constexpr int TP = SUB == 4 ? 4 : 8;              // tile edge in pixels
+  const uint32_t tws = SUB == 4 ? 2u : P.tile_w_shift, ths = SUB == 4 ? 2u : P.tile_h_shift;  // tile = (1 << tws) x (1 << ths) pixels
   const uint32_t px = SUB == 4 ? lane >> 2 : lane;  // pixel of the tile this lane works for
   const uint32_t sub = SUB == 4 ? lane & 3u : 0u;
   Counters<STATS> ct;
@@ -512,10 +516,10 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
         up.c = up.r = up.x = up.y = 0; up.halo = true; up.valid = active;
         if (active) up = place_of_unit(P, unit);
       } else {
-        up.c = (int)(tx * TP + (px % TP));
-        up.r = (int)(ty * TP + (px / TP));
+        up.c = (int)((tx << tws) + (px & ((1u << tws) - 1u)));
+        up.r = (int)((ty << ths) + (px >> tws));
         up.halo = false;
-        active = up.c < P.w && up.r < P.h;
+        active = px < (1u << (tws + ths)) && up.c < P.w && up.r < P.h;
         up.valid = active;
         up.x = P.x0 + up.c;
         up.y = image_row(P, up.r);
@@ -733,48 +737,151 @@ __global__ void __launch_bounds__(kBlock) object_query_kernel(const ObjectQueryP
 }
 
 // For every tile row that starts a chain of its own (its predecessor in the FRAME is not the end of the tile row above:
-// first row of a stripe, any row of a sub-rectangle, a tile that does not start at the frame's first pixel): the last
-// kHaloChain frame pixels before the row's first pixel that touch the stack, i.e. whose primary ray (any of the pixel's
-// samples) gets past the root test of bvh.cpp:203-205.  They are rendered in front of the row, for their leftovers only;
-// the first of them starts on an empty stack, which is exact if the frame's first touching pixel is among them and
-// otherwise assumes that what a pixel leaves does not depend on a leftover kHaloChain pixels back (every link of that
-// chain would have to change its successor's first hit).  One wave per row walks back 64 pixels at a time.
-__global__ void __launch_bounds__(kBlock) halo_find_kernel(const RenderParams P, uint32_t* halo_pix) {
+// first row of a stripe, any row of a sub-rectangle, a tile that does not start at the frame's first pixel): the frame
+// pixels in front of the row whose leftovers have to be known for the row's first pixel to start on the right stack.
+//
+// A pixel "touches" the stack if the primary ray of one of its samples gets past the root test (bvh.cpp:203-205).  What
+// the row starts on is the leftover of the last touching pixel before it, which depends on ITS predecessor's leftover,
+// and so on back to the frame's first pixel - but only through the result of each pixel's first closest hit
+// (handoff.hpp).  The chain can therefore be cut at a pixel whose first closest hit provably does not depend on the
+// stack it finds.  The stale entries of a found stack are popped AFTER the query's own traversal and the popped
+// subtrees are walked with the query's ray (bvh.cpp:256-265); that changes the result only if (a) one of the primitive
+// tests it runs returns a hit nearer than the own traversal's, or (b) a sphere test re-normalises the ray's direction
+// (scene.cpp:156, ray.h:16-18).  So a pixel is CERTIFIED if, after its own traversal on an empty stack,
+//   (a) NO primitive of the scene - all of them are tested, whatever boxes they sit in - is hit nearer than tmin by the
+//       ray as the traversal left it, and
+//   (b) the scene has no sphere, or normalising that ray's direction once more leaves its bits unchanged (then every
+//       further normalisation is the identity).
+// Under (a) and (b) no sequence of stale subtree walks can change tmin, the hit or the direction, whatever the stack
+// held: the pixel rendered on an empty stack is the pixel of the serial frame, its leftover included.  The kernel walks
+// back from the row, takes the touching pixels most recent first, and stops at the first one it can certify (or at the
+// frame's first touching pixel, whose stack IS empty); the pixels it collected are rendered in front of the row for
+// their leftovers, the oldest on an empty stack, each next one checked against its predecessor's leftover like any
+// other unit.  If `max_chain` (<= kHaloChain) pixels are collected without a certificate and an older touching pixel
+// exists, the row cannot be started exactly: kHoErrHalo is raised and the call fails (P3D_ERR_CAPACITY) instead of
+// returning a frame that is only probably right.
+//
+// One workgroup per row.  Every thread looks at one pixel of the kHaloFindThreads before the row; candidates are taken
+// one at a time: wave 0 runs the own traversal (all lanes the same ray), all threads share the all-primitives test.
+constexpr int kHaloFindThreads = 1024;
+struct HaloFindShared {
+  unsigned long long touched[kHaloFindThreads / kBlock];
+  float tmin, dx, dy, dz;
+  uint32_t settled, closer;
+};
+__device__ __forceinline__ bool pixel_first_touching_ray(const RenderParams& P, const NodeRec& root, long long f, RayS& ray) {
+  const DevScene& sc = P.sc;
+  const int res_x = sc.cam.res_x, SPP = P.antialiasing ? (int)P.spp_sqrt : 1;
+  const int x = (int)(f % res_x), y = (int)(f / res_x);
+  for (int s = 0; s < SPP * SPP; ++s) {
+    Rng rng;
+    rng.state = 0; rng.inc = 1;
+    if (P.antialiasing) rng.seed_stream(P.seed, (uint32_t)(y * res_x + x), (uint32_t)s);
+    F3 o, d;
+    make_primary(P, sc.cam, x, y, s / SPP, s % SPP, rng, o, d);
+    ray_set(ray, o, d);
+    float t;
+    if (aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, t, false)) return true;
+  }
+  return false;
+}
+// Which rows of a tile start a chain of their own: a function of the tile alone, worked out on the launch stream so
+// that two tiles queued on one stream cannot see each other's flags.  Also resets the verdict of the search that follows.
+struct RowChainParams {
+  uint8_t* chain;
+  uint32_t* verdict;
+  int32_t rows, x0, y0, w, res_x, sh, ss;
+};
+__global__ void __launch_bounds__(256) row_chain_kernel(const RowChainParams C) {
+  const int r = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (r == 0) *C.verdict = 0;
+  if (r >= C.rows) return;
+  auto image_y = [&](int row) { return (long long)C.y0 + (long long)(row / C.sh) * C.sh * C.ss + (row % C.sh); };
+  const long long y = image_y(r);
+  const bool full_width = C.x0 == 0 && C.w == C.res_x;
+  C.chain[r] = r == 0 ? !(C.x0 == 0 && y == 0) : !(full_width && y == image_y(r - 1) + 1);
+}
+
+__global__ void __launch_bounds__(kHaloFindThreads) halo_find_kernel(const RenderParams P, uint32_t* halo_pix, uint32_t* verdict, uint32_t max_chain,
+                                                                     uint32_t has_spheres, uint32_t window, uint32_t backing_stride) {
+  extern __shared__ float4 smem[];  // wave 0's node stack: window * 64 entries
+  __shared__ HaloFindShared sh;
   const Handoff& H = P.hand;
-  const uint32_t row = blockIdx.x, lane = threadIdx.x;
+  const uint32_t row = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (row >= H.rows || !H.row_chain[row]) return;
   const DevScene& sc = P.sc;
-  const int res_x = sc.cam.res_x;
-  const long long f0 = (long long)image_row(P, (int)row) * res_x + P.x0;  // the row's first pixel: search below it
+  const long long f0 = (long long)image_row(P, (int)row) * sc.cam.res_x + P.x0;  // the row's first pixel: search below it
   const NodeRec root = load_node(sc.nodes, 0);
-  const int SPP = P.antialiasing ? (int)P.spp_sqrt : 1;
+  Counters<false> ct;
   uint32_t found = 0;
-  for (long long base = f0; base > 0 && found < kHaloChain; base -= kBlock) {
-    const long long f = base - 1 - (long long)lane;  // lane 0 looks at the most recent pixel
-    bool touched = false;
-    if (f >= 0) {
-      const int x = (int)(f % res_x), y = (int)(f / res_x);
-      for (int s = 0; s < SPP * SPP && !touched; ++s) {
-        Rng rng;
-        rng.state = 0; rng.inc = 1;
-        if (P.antialiasing) rng.seed_stream(P.seed, (uint32_t)(y * res_x + x), (uint32_t)s);
-        F3 o, d;
-        make_primary(P, sc.cam, x, y, s / SPP, s % SPP, rng, o, d);
-        RayS ray;
-        ray_set(ray, o, d);
-        float t;
-        touched = aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, t, false);
+  bool certified = false, older_exists = false;
+  for (long long base = f0; base > 0 && !certified && !older_exists; base -= kHaloFindThreads) {
+    const long long f = base - 1 - (long long)tid;  // thread 0 looks at the most recent pixel
+    RayS ray;
+    const bool touched = f >= 0 && pixel_first_touching_ray(P, root, f, ray);
+    const unsigned long long m = __ballot(touched);
+    if (lane == 0) sh.touched[wave] = m;
+    __syncthreads();
+    for (uint32_t w = 0; w < kHaloFindThreads / kBlock && !certified && !older_exists; ++w) {
+      unsigned long long mask = sh.touched[w];
+      while (mask && !certified && !older_exists) {  // workgroup-uniform
+        const int l = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        if (found == max_chain) {  // the chain is full and here is a touching pixel it would still need
+          older_exists = true;
+          break;
+        }
+        const long long pix = base - 1 - (long long)(w * kBlock + (uint32_t)l);
+        if (tid == 0) halo_pix[row * kHaloChain + (kHaloChain - 1 - found)] = (uint32_t)pix;
+        ++found;
+        // ---- certificate ----
+        pixel_first_touching_ray(P, root, pix, ray);  // (every thread: the same ray)
+        if (wave == 0) {
+          Stack st;
+          st.base = lds_stack_ptr(smem, 0, lane);
+          st.spill = P.spill;
+          st.tid = blockIdx.x * kBlock + lane;
+          st.spill_stride = backing_stride;
+          st.cap = (int)window;
+          stack_clear(st);
+          F3 hp;
+          Geom g;
+          float tmin = FLT_MAX;
+          RayS left;
+          bvh_closest<true>(sc, st, ray, hp, g, ct, nullptr, &tmin, &left);
+          if (lane == 0) {
+            sh.tmin = tmin;
+            sh.dx = left.d.x; sh.dy = left.d.y; sh.dz = left.d.z;
+            sh.settled = same_bits(normalized(left.d), left.d) ? 1u : 0u;
+            sh.closer = 0;
+          }
+        }
+        __syncthreads();
+        const float tmin = sh.tmin;
+        const bool settled = sh.settled != 0;
+        bool closer = false;
+        if (settled || !has_spheres) {
+          RayS r = ray;
+          r.d = f3(sh.dx, sh.dy, sh.dz);
+          r.inv = f3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+          r.odd_inv = inv_is_odd(r.inv);
+          r.settled = settled;  // a settled direction is returned as it is by the sphere test (ray.h:16-18 would give the same bits)
+          for (uint32_t i = tid; i < sc.n_objs && !closer; i += kHaloFindThreads) {
+            const Geom g = load_geom(sc.ogeom, i);
+            float t;
+            closer = intercepts(g, r, t, ct) && t < tmin;
+          }
+        }
+        if (closer) sh.closer = 1;  // (benign race: every writer stores the same value)
+        __syncthreads();
+        certified = (settled || !has_spheres) && sh.closer == 0;
+        __syncthreads();
       }
     }
-    unsigned long long mask = __ballot(touched);
-    while (mask && found < kHaloChain) {  // wave-uniform
-      const int l = __ffsll((long long)mask) - 1;
-      if (lane == 0) halo_pix[row * kHaloChain + (kHaloChain - 1 - found)] = (uint32_t)(base - 1 - l);
-      ++found;
-      mask &= mask - 1;
-    }
+    __syncthreads();
   }
-  if (lane < kHaloChain - found) halo_pix[row * kHaloChain + lane] = kNoUnit;
+  if (older_exists && !certified && tid == 0) atomicOr(verdict, kHoErrHalo);
+  if (tid < kHaloChain - found) halo_pix[row * kHaloChain + tid] = kNoUnit;
 }
 
 // Round 1 of the hand-off for a whole launch: every unit that touched the stack and whose predecessor left something
@@ -792,8 +899,9 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
   if (halo_block) {
     active = halo_unit_of_lane(P, lane, unit);
   } else {
-    const int c = (int)(tx * 8 + (lane % 8)), r = (int)(ty * 8 + (lane / 8));
-    active = c < P.w && r < P.h;
+    const uint32_t tws = P.tile_w_shift, ths = P.tile_h_shift;
+    const int c = (int)((tx << tws) + (lane & ((1u << tws) - 1u))), r = (int)((ty << ths) + (lane >> tws));
+    active = lane < (1u << (tws + ths)) && c < P.w && r < P.h;
     unit = (uint32_t)(P.row0 + r) * H.row_units + H.halo + (uint32_t)c;
   }
   // which lanes have anything to re-trace is known before the scene is staged: most waves leave here

@@ -100,6 +100,18 @@ inline uint32_t redo_lanes() {
 }
 uint32_t g_debug_trip_bound = 0;  // tests: force the sample hand-out loops of the SUB = 4 kernels to give up early
 uint32_t g_debug_max_rounds = 0;  // tests: round bound of the hit_stack hand-off (0 = the real one)
+uint32_t g_debug_halo_chain = 0;  // tests: pixels halo_find_kernel may collect in front of a row (0 = kHaloChain)
+
+// Tile of a wave of the one-lane-per-pixel Whitted kernels over a scene traversed from L2 (see p3d_render_tile_device).
+// P3D_TILE_SHAPE = 88 | 84 | 44 in the environment overrides the rule (experiments).
+void tile_shape(uint64_t pixels, uint32_t& w, uint32_t& h) {
+  static const int forced = [] { const char* e = getenv("P3D_TILE_SHAPE"); return e ? atoi(e) : 0; }();
+  int shape = forced;
+  if (shape != 88 && shape != 84 && shape != 44) shape = 88;
+  w = shape == 44 ? 4 : 8;
+  h = shape == 88 ? 8 : 4;
+  (void)pixels;
+}
 constexpr size_t kSchedCacheEntries = 16;
 constexpr uint32_t kSchedMinTiles = 8192;  // with fewer tiles than ~2 per wave slot nearly all start at once anyway
 
@@ -124,7 +136,9 @@ struct p3d_scene {
   Scratch levels, spill, deferred, wf_rays, wf_keys, wf_sorted, wf_final, out_rgb, out_hit, out_rgb8, q_in, q_out;
   // P3D_STACK_LITERAL (csrc/handoff.hpp): leftovers, per-unit records, work lists, counters
   Scratch ho_entries, ho_meta, ho_first, ho_first_sample, ho_touched, ho_lists, ho_counters, ho_row_chain, ho_halo_pix, ho_ucount;
-  std::vector<int32_t> ho_chain_key;     // tile the row_chain flags on the device were computed for
+  std::vector<int64_t> ho_chain_key;     // what the row_chain flags and halo pixels on the device were worked out for
+  bool has_spheres = false;              // (halo_find_kernel: only a sphere test re-normalises a ray)
+  uint32_t* d_halo_verdict = nullptr;    // kHoErrHalo if the memoised halo search could not start some row exactly
   float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};  // box of BVH node 0 (bins of the per-level ray queue)
   bool zero_weight_reflections = false;  // some material is transmissive AND reflective (main.cpp:282,290-300)
   unsigned long long* d_stats = nullptr;
@@ -159,6 +173,7 @@ void p3d_scene_destroy(p3d_scene* s) {
   s->ho_entries.release(); s->ho_meta.release(); s->ho_first.release(); s->ho_first_sample.release(); s->ho_touched.release();
   s->ho_lists.release(); s->ho_counters.release(); s->ho_row_chain.release(); s->ho_halo_pix.release(); s->ho_ucount.release();
   if (s->d_status) (void)hipFree(s->d_status);
+  if (s->d_halo_verdict) (void)hipFree(s->d_halo_verdict);
   s->out_rgb8.release(); s->q_in.release(); s->q_out.release();
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -414,6 +429,9 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
   P3D_HIP(hipMalloc((void**)&s->d_stats, kNumStats * sizeof(unsigned long long)));
   P3D_HIP(hipMalloc((void**)&s->d_status, sizeof(uint32_t)));
   P3D_HIP(hipMemset(s->d_status, 0, sizeof(uint32_t)));
+  P3D_HIP(hipMalloc((void**)&s->d_halo_verdict, sizeof(uint32_t)));
+  P3D_HIP(hipMemset(s->d_halo_verdict, 0, sizeof(uint32_t)));
+  for (uint32_t i = 0; i < d->n_prims; ++i) s->has_spheres = s->has_spheres || d->prims[i].type == P3D_PRIM_SPHERE;
   for (uint32_t i = 0; i < d->n_materials; ++i)
     if (d->materials[i].transmittance != 0 && d->materials[i].reflection > 0) s->zero_weight_reflections = true;
   P3D_HIP(hipEventCreate(&s->ev0));
@@ -591,6 +609,7 @@ int check_status(p3d_scene* s) {
   if (h & kHoErrTrips) what += " sample hand-out loop reached its trip bound (pixels would miss samples);";
   if (h & kHoErrLeftoverCap) what += " a hit_stack leftover outgrew its slot;";
   if (h & kHoErrNoFixedPoint) what += " hit_stack hand-off did not reach a fixed point;";
+  if (h & kHoErrHalo) what += " a row of a stripe / sub-rectangle could not be started on the hit_stack the serial frame hands it (no pixel in front of it certifiably independent of its own incoming stack): render it with more rows in front, as part of the whole frame, or with P3D_STACK_PER_PIXEL;";
   if (h & kHoErrList) what += " a work list of the hit_stack hand-off or a ray queue segment of the per-level launches overflowed;";
   return fail(P3D_ERR_CAPACITY, "device-detected error:" + what);
 }
@@ -706,15 +725,23 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // unless the samples of a pixel have to hand the stack to each other in order (LITERAL)
   const bool sub4 = (pt && cfg->spp_sqrt >= kPtSub4MinSppSqrt) ||
                     (!pt && !literal && !lds_scene && cfg->antialiasing && cfg->spp_sqrt >= kWhittedSub4MinSppSqrt);
-  const uint32_t tp = sub4 ? 4 : 8;  // tile edge in pixels
   // ... and behind the node stack: the sample ring of the four-lanes-per-pixel kernels, or the cold shading state of the
   // Whitted kernels that traverse the scene from L2 without anti-aliasing (ColdState<true>, device_core.hpp)
   const bool cold_lds = !pt && !lds_scene && !cfg->antialiasing;
+  // Pixels per wave.  Four lanes per pixel: 4x4.  One lane per pixel: 8x8, or - Whitted over a scene traversed from L2,
+  // where a wave is as long as the slowest of its lanes in every query - 8x4 / 4x4 when the launch has too few 8x8 tiles
+  // to keep the wave slots busy for several rounds (stripes of a multi-GPU frame, small frames): quarter waves are
+  // shorter and four times as many, at the price of issue slots the chip then has to spare (tile_shape()).
+  uint32_t tpw = sub4 ? 4 : 8, tph = sub4 ? 4 : 8;
+  if (!sub4 && !pt && !lds_scene && !cfg->antialiasing && cfg->chain_launch != P3D_CHAIN_PER_LEVEL) tile_shape((uint64_t)tile->w * tile->h, tpw, tph);
+  const uint32_t tp = tph;  // rows per tile band
+  P.tile_w_shift = tpw == 8 ? 3 : 2;
+  P.tile_h_shift = tph == 8 ? 3 : 2;
   const size_t lds_bytes = (size_t)P.lds_scene_f4 * sizeof(float4) + (size_t)cap * kBlock * sizeof(uint2) +
                            (sub4 ? sizeof(PtPixelShared) : 0) + (cold_lds ? (size_t)kColdDwords * kBlock * sizeof(float) : 0);
 
   // rows per launch: whole 8-row tile bands, at most kMaxLaunchThreads threads
-  const uint32_t tiles_x = ((uint32_t)tile->w + tp - 1) / tp;
+  const uint32_t tiles_x = ((uint32_t)tile->w + tpw - 1) / tpw;
   // per-thread global scratch: Whitted level records (+ the zero-weight reflection rays a LITERAL launch puts aside),
   // or the path tracer's two deferred dielectric branches
   const uint32_t levels = pt ? 2 * 3 : (uint32_t)cfg->max_depth;
@@ -723,7 +750,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // Whitted without anti-aliasing over a BVH read from L2.  Not for the zero-weight reflection rays of LITERAL frames
   // (they make the chain a tree) and not for a grid or the object loop (no stack record to carry between launches).
   bool per_level = !pt && !cfg->antialiasing && cfg->accel == P3D_ACCEL_BVH && !lds_scene && cfg->max_depth >= 1 && cfg->max_depth <= 64 &&
-                   !(literal && s->zero_weight_reflections) && cfg->chain_launch == P3D_CHAIN_PER_LEVEL && tp == 8;
+                   !(literal && s->zero_weight_reflections) && cfg->chain_launch == P3D_CHAIN_PER_LEVEL;
   if (cfg->chain_launch == P3D_CHAIN_PER_LEVEL && !per_level)
     return fail(P3D_ERR_UNSUPPORTED, "chain_launch = PER_LEVEL needs Whitted without anti-aliasing over a BVH too big for LDS (and no transmissive + reflective material under P3D_STACK_LITERAL)");
   // per-level launches keep their level records per pixel, not per launch thread
@@ -748,9 +775,10 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     const uint32_t groups = (ntiles + 8 * xcd_chunk - 1) / (8 * xcd_chunk);
     return groups * 8 * xcd_chunk;
   };
-  // Cost-ordered tiles (DESIGN.md "Tile schedule"): where the frame order leaves a tail of a few
-  // long-running tiles — Whitted chains over an LDS-staged scene, more tiles than wave slots.
-  const bool sched_ok = lds_scene && cfg->tile_order == P3D_TILE_ORDER_COST && cfg->max_depth > 0;
+  // Cost-ordered tiles (DESIGN.md "Tile schedule"): the frame order leaves a tail of a few long-running tiles.  Since
+  // round 3 also for scenes traversed from L2 (100k triangles 2048x2048 18.25 -> 16.9 ms, 1024x1024 7.2 -> 6.5 ms; in
+  // round 2, with child pairs straddling cache lines, the lost L2 locality cost more than the tail: 7.2 -> 7.5-7.9 ms).
+  const bool sched_ok = cfg->tile_order == P3D_TILE_ORDER_COST && cfg->max_depth > 0;
   // LITERAL: workgroups behind the tile grid of the first launch render the halo chains (8 chains of 8 pixels per wave)
   const uint32_t halo_blocks_max = literal ? ((uint32_t)tile->h * kHaloChain + kBlock - 1) / kBlock : 0;
   const uint32_t max_threads = (blocks_for(tiles_x * bands_per_launch) + halo_blocks_max) * kBlock;
@@ -759,7 +787,9 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // megakernel and index [level][launch thread] with up to max_threads threads, whatever the size of the tile
   const size_t level_cols = per_level ? std::max<size_t>(tile_units, literal ? (size_t)max_threads : 0) : (size_t)max_threads;
   if (int rc = s->levels.ensure(std::max<size_t>(16, (size_t)levels * level_cols * sizeof(float4)))) return rc;
-  if (int rc = s->spill.ensure(std::max<size_t>(16, (size_t)spill_entries * max_threads * sizeof(uint2)))) return rc;
+  // (+ halo_find_kernel: one traversal per chain row on an empty stack, window of 8 entries, the rest of a tree path here)
+  const size_t halo_backing = literal && s->bvh_max_depth > 8 ? (size_t)s->bvh_max_depth * tile->h * kBlock * sizeof(uint2) : 0;
+  if (int rc = s->spill.ensure(std::max<size_t>(16, std::max((size_t)spill_entries * max_threads * sizeof(uint2), halo_backing)))) return rc;
   if (int rc = s->deferred.ensure(std::max<size_t>(16, (size_t)deferred * max_threads * sizeof(float4)))) return rc;
   P.levels = (float4*)s->levels.p;
   P.spill = (uint2*)s->spill.p;
@@ -824,11 +854,6 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     if (any_chain) {
       if (int rc = s->ho_row_chain.ensure((size_t)tile->h)) return rc;
       if (int rc = s->ho_halo_pix.ensure((size_t)tile->h * kHaloChain * 4)) return rc;
-      const std::vector<int32_t> key = {tile->x0, tile->y0, tile->w, tile->h, tile->stripe_h, tile->stripe_stride, cam.res_x, cam.res_y};
-      if (key != s->ho_chain_key) {  // flags unchanged for the same tile: frames of a sequence upload them once
-        P3D_HIP(hipMemcpy(s->ho_row_chain.p, chain.data(), chain.size(), hipMemcpyHostToDevice));
-        s->ho_chain_key = key;
-      }
       H.row_chain = (const uint8_t*)s->ho_row_chain.p;
       H.halo_pix = (const uint32_t*)s->ho_halo_pix.p;
     }
@@ -845,25 +870,40 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     ho_counters = (uint32_t*)s->ho_counters.p;
     H.counters = ho_counters;
   }
+  if (stats && literal) P3D_HIP(hipEventRecord(s->ev0, st));  // kernel_ms of a LITERAL frame is the whole frame: halo search (when not memoised) and clear included
+  uint32_t halo_blocks = 0;
+  if (literal && H.halo) {
+    halo_blocks = (H.rows * kHaloChain + kBlock - 1) / kBlock;
+    // The chain flags and the pixels in front of every chain row are a function of the tile and of what shapes the
+    // primary rays (the scene and its camera are fixed): worked out by two launches on this stream when any of that
+    // changes, kept otherwise (the frames of a sequence find them ready).
+    const uint32_t max_chain = g_debug_halo_chain ? std::min<uint32_t>(g_debug_halo_chain, kHaloChain) : kHaloChain;
+    const std::vector<int64_t> key = {tile->x0, tile->y0, tile->w, tile->h, tile->stripe_h, tile->stripe_stride, cam.res_x, cam.res_y,
+                                      cfg->antialiasing ? 1 : 0, cfg->antialiasing ? (int64_t)cfg->spp_sqrt : 1, (int64_t)cfg->seed,
+                                      cfg->sample_mode, cfg->depth_of_field, cfg->sample_disk, max_chain, (int64_t)(intptr_t)st};
+    if (key != s->ho_chain_key) {
+      RowChainParams C{(uint8_t*)s->ho_row_chain.p, s->d_halo_verdict, tile->h, tile->x0, tile->y0, tile->w, cam.res_x, sh, ss};
+      hipLaunchKernelGGL(row_chain_kernel, dim3(((uint32_t)tile->h + 255) / 256), dim3(256), 0, st, C);
+      P3D_HIP(hipGetLastError());
+      P.x0 = tile->x0; P.y0 = tile->y0; P.row0 = 0; P.w = tile->w; P.h = tile->h;
+      const uint32_t find_window = 8;  // LDS entries of the one traversal at a time each workgroup runs; deeper ones in P.spill
+      hipLaunchKernelGGL(halo_find_kernel, dim3(H.rows), dim3(kHaloFindThreads), (size_t)find_window * kBlock * sizeof(uint2), st, P,
+                         (uint32_t*)s->ho_halo_pix.p, s->d_halo_verdict, max_chain, s->has_spheres ? 1u : 0u, find_window, H.rows * kBlock);
+      P3D_HIP(hipGetLastError());
+      s->ho_chain_key = key;
+    }
+  }
   if (literal || per_level || stats) {  // one clear launch at the head of the frame: statistics, counters, touched bits
     ClearParams C{};
     if (stats) { C.p[0] = (uint32_t*)s->d_stats; C.n[0] = kNumStats * 2; }
     if (literal || per_level) { C.p[1] = ho_counters; C.n[1] = counter_words; }
     if (literal) { C.p[2] = (uint32_t*)s->ho_touched.p; C.n[2] = (uint32_t)(touched_bytes / 4); }
-    // kernel_ms of a LITERAL frame is the whole frame, clear included; otherwise the clear is there for the counters
-    // only and stays outside
-    if (stats && literal) P3D_HIP(hipEventRecord(s->ev0, st));
+    if (literal && H.halo) { C.halo_verdict = s->d_halo_verdict; C.status = s->d_status; }
+    // (not LITERAL: the clear is there for the counters only and stays outside kernel_ms)
     const uint32_t words = std::max(C.n[0], std::max(C.n[1], C.n[2]));
     hipLaunchKernelGGL(clear_kernel, dim3(std::min<uint32_t>(256, (words + 255) / 256)), dim3(256), 0, st, C);
     P3D_HIP(hipGetLastError());
     if (stats && !literal) P3D_HIP(hipEventRecord(s->ev0, st));
-  }
-  uint32_t halo_blocks = 0;
-  if (literal && H.halo) {
-    halo_blocks = (H.rows * kHaloChain + kBlock - 1) / kBlock;
-    P.x0 = tile->x0; P.y0 = tile->y0; P.row0 = 0; P.w = tile->w; P.h = tile->h;
-    hipLaunchKernelGGL(halo_find_kernel, dim3(H.rows), dim3(kBlock), 0, st, P, (uint32_t*)s->ho_halo_pix.p);
-    P3D_HIP(hipGetLastError());
   }
   if (stats && literal) P3D_HIP(hipEventRecord(s->ev_p1, st));  // pass1_ms: the speculative pass on its own
   // pass: 0 = the render launches (LITERAL: pass 1, everything on an empty stack); 1 = LITERAL only: the check launches
@@ -1005,6 +1045,10 @@ int p3d_debug_set_trip_bound(uint32_t trips) {
 }
 int p3d_debug_set_max_rounds(uint32_t rounds) {
   g_debug_max_rounds = rounds;
+  return P3D_OK;
+}
+int p3d_debug_set_halo_chain(uint32_t pixels) {
+  g_debug_halo_chain = pixels;
   return P3D_OK;
 }
 

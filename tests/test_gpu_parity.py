@@ -422,6 +422,45 @@ def test_sample_loop_backstop_is_an_error_not_a_darker_pixel():
     assert (again.view(np.uint32) == good.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("scene,legacy,res", [("balls_low.p3f", False, (256, 256)), ("balls_medium.p3f", True, (128, 128))])
+def test_row_starts_are_certified_or_the_call_fails(scene, legacy, res):
+    """A stripe or sub-rectangle starts every row that has no predecessor in the tile on the leftover of the frame
+    pixels in front of it.  halo_find_kernel walks back to a pixel whose own first closest hit provably does not depend
+    on the stack it finds (no primitive of the scene nearer than its hit, direction stable under re-normalisation) and
+    renders the chain from there; if it cannot find one among the pixels it may collect, the call FAILS instead of
+    returning a frame that is only probably right.  Shrinking that allowance to one pixel makes the detector fire on a
+    sphere scene (the pixel right in front of some row is not certifiable); with the real allowance every stripe and
+    sub-rectangle is the full frame bit for bit."""
+    dev, _ = _pair(scene_path(scene), res=res, legacy=legacy, grid=False)
+    cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4)
+    full, full_hit, _ = dev.render(cfg)
+    tiles = [p3d.stripe_tile(res, rank, 4, 8) for rank in range(4)] + [p3d.Tile(res[0] // 3, res[1] // 4, res[0] // 2, res[1] // 2, 0, 1)]
+    L = p3d.lib()
+    fired = []
+    for allowance in (1, 2, 3):
+        try:
+            L.p3d_debug_set_halo_chain(allowance)
+            n = 0
+            for t in tiles:
+                try:
+                    dev.render(cfg, tile=t)
+                except p3d.P3DError as e:
+                    assert e.code == -4 and "could not be started" in str(e)
+                    n += 1
+            fired.append(n)
+        finally:
+            L.p3d_debug_set_halo_chain(0)
+    assert fired[0] > 0 and fired[0] >= fired[1] >= fired[2], fired  # fewer pixels allowed, more rows that cannot be certified
+    for rank in range(4):
+        rgb, hit, _ = dev.render(cfg, tile=tiles[rank])
+        rows = p3d.stripe_rows(res, rank, 4, 8)
+        assert (rgb.view(np.uint32) == full[rows].view(np.uint32)).all() and (hit == full_hit[rows]).all()
+    t = tiles[4]
+    rgb, hit, _ = dev.render(cfg, tile=t)
+    assert (rgb.view(np.uint32) == full[t.y0:t.y0 + t.h, t.x0:t.x0 + t.w].view(np.uint32)).all()
+    assert dev.status() == 0
+
+
 def test_hand_off_that_runs_out_of_rounds_is_an_error_also_without_stats():
     """The hit_stack hand-off iterates its work lists to a fixed point; a list that is still not empty after the round
     bound means the frame is not the serial one.  That must fail the call - also on the asynchronous path (device
