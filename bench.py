@@ -42,6 +42,8 @@ SIMDS = 256 * 4        # 256 CUs x 4 SIMDs
 VALU_CYCLES = 2        # a wave64 VALU instruction issues over 2 cycles on a SIMD-32 (MI355X_MICROARCH.md "Wave scheduling";
 #                        4 cycles is what ONE wave alone sustains, and what round 1 mistook for the SIMD's rate)
 HBM_PEAK_GBPS = 8000.0
+LDS_PEAK_GBPS = 256 * 128 * CLOCK_HZ / 1e9  # 128 B per clock and CU
+TIMED_REPEATS = 5      # the timed loop (exactly --steps steps, barrier + synchronize on both sides) is run this often: median counted, all reported
 
 
 def parse():
@@ -70,6 +72,9 @@ def parse():
     ap.add_argument("--gather-batch", type=int, default=None,
                     help="N > 1: frames rendered back to back into one buffer per collective (default 1; cfg2w: 8 — a "
                          "0.3 ms frame cannot pay for a collective launch of its own)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N > 1 code path (process group, stripes, one collective per frame, assemble on rank 0) also "
+                         "with a single rank: exercises the RCCL gather on a one-GPU box")
     ap.add_argument("--gather", default=None, choices=["u8", "f32"],
                     help="N>1: what rank 0 collects per frame: float RGB + hit IDs (16 B/px, default) or the u8 image (3 B/px, cfg2w default)")
     return ap.parse_args()
@@ -124,9 +129,9 @@ def kernel_source_hash():
 
 
 def pmc_summary(workload, stack_mode):
-    """profiles/r02/<workload>_<stack mode>_pmc_summary.json (profiles/r02_profile_recipe.sh) if it was collected
+    """profiles/r03/<workload>_<stack mode>_pmc_summary.json (profiles/r03_profile_recipe.sh) if it was collected
     from exactly these kernel sources, else None: stale counters are not quoted."""
-    path = os.path.join(ROOT, "profiles", "r02", "%s_%s_pmc_summary.json" % (workload, stack_mode))
+    path = os.path.join(ROOT, "profiles", "r03", "%s_%s_pmc_summary.json" % (workload, stack_mode))
     if not os.path.exists(path):
         return None, "no PMC summary committed for this workload (%s)" % os.path.relpath(path, ROOT)
     s = json.load(open(path))
@@ -150,19 +155,21 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                      "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    dist_on = world > 1 or args.force_dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the hot path has no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    host_staged = world > 1 and args.backend == "gloo"
+    host_staged = dist_on and args.backend == "gloo"
 
-    workload = args.workload or ("cfg2" if world == 1 else "cfg4")
+    workload = args.workload or ("cfg2" if not dist_on else "cfg4")
     gather = args.gather or ("u8" if workload == "cfg2w" else "f32")
     scene_path, cfg, base, desc = workload_setup(workload, p3d)
     cfg.tile_order = p3d.TILE_ORDER_COST if args.tile_order == "cost" else p3d.TILE_ORDER_FRAME
@@ -179,12 +186,12 @@ def main():
     if workload == "cfg5":
         hs.set_lens(10.0, 1.0)
     dev = p3d.DeviceScene(hs, bvh=True, device=dev_index)
-    tile = p3d.stripe_tile((res, res), rank, world, stripe_h) if world > 1 else dev.full_tile()
+    tile = p3d.stripe_tile((res, res), rank, world, stripe_h) if dist_on else dev.full_tile()
     n_local = tile.w * tile.h
     stream = torch.cuda.current_stream()
     # frames in flight (N = 1): frame i is rendered by scene i % nfl on stream i % nfl into output buffers of its own
-    nfl = max(1, args.frames_in_flight if args.frames_in_flight is not None else (4 if world == 1 else 1))
-    if world > 1:
+    nfl = max(1, args.frames_in_flight if args.frames_in_flight is not None else (4 if not dist_on else 1))
+    if dist_on:
         nfl = 1
     # (slot 0 stays on the default stream: HIP spreads streams over 4 hardware queues, the default stream has one to
     # itself and the pool streams share the other three — a fourth pool stream would queue behind the first one's launches)
@@ -194,7 +201,7 @@ def main():
     # allocation, 16 B/px) and the gamma-corrected u8 image (img_Data, 3 B/px).  Rank 0 collects one
     # of the two (--gather) for EVERY frame; B = --gather-batch consecutive frames share one
     # collective (their buffers are adjacent), double-buffered against the rendering of the next B.
-    B = (args.gather_batch or (8 if workload == "cfg2w" else 1)) if world > 1 else 1
+    B = (args.gather_batch or (8 if workload == "cfg2w" else 1)) if dist_on else 1
     packed_sz, u8_sz = p3d.packed_bytes(n_local), n_local * 3
 
     def new_bufs():
@@ -209,10 +216,10 @@ def main():
     gdev = "cpu" if host_staged else "cuda"
     # (every rank keeps receive buffers: only rank 0 uses them unless the backend forces all_gather)
     gathered = ([[torch.empty(pick(bufs[0]).shape, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
-                if world > 1 else None)
-    frame8 = torch.empty((B, res, res, 3), dtype=torch.uint8, device=gdev) if rank == 0 and world > 1 else None
-    frame_rgb = torch.empty((B, res, res, 3), dtype=torch.float32, device=gdev) if rank == 0 and world > 1 else None
-    frame_hit = torch.empty((B, res, res), dtype=torch.int32, device=gdev) if rank == 0 and world > 1 else None
+                if dist_on else None)
+    frame8 = torch.empty((B, res, res, 3), dtype=torch.uint8, device=gdev) if rank == 0 and dist_on else None
+    frame_rgb = torch.empty((B, res, res, 3), dtype=torch.float32, device=gdev) if rank == 0 and dist_on else None
+    frame_hit = torch.empty((B, res, res), dtype=torch.int32, device=gdev) if rank == 0 and dist_on else None
 
     def assemble(slot):
         if gather == "u8":
@@ -236,7 +243,7 @@ def main():
             handles[slot] = None
 
     def send(slot):
-        if world > 1 and filled[slot]:
+        if dist_on and filled[slot]:
             payload = pick(bufs[slot]).cpu() if host_staged else pick(bufs[slot])
             handles[slot], _ = p3d.gather_frame(payload, (res, res), rank, world, stripe_h, 0, gathered[slot], async_op=True)
             in_flight[slot], filled[slot] = filled[slot], 0
@@ -267,7 +274,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -283,7 +290,7 @@ def main():
         drain()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -298,7 +305,8 @@ def main():
     render_into(bufs[0], tile, cfg, stats=cold)
     for sc_, st_ in flight[1:]:  # the other slots record their tile schedules outside the timed region too
         render_into(bufs[0], tile, cfg, stats=p3d.Stats(), scene=sc_, on=st_)
-    dt = timed_loop(cfg)
+    dts = sorted(timed_loop(cfg) for _ in range(TIMED_REPEATS))
+    dt = dts[len(dts) // 2]
 
     # what the timed frames left in their slots must be, bit for bit, the frame one scene renders on its own
     flight_check = None
@@ -329,9 +337,10 @@ def main():
     st = p3d.Stats()
     render_into(bufs[0], tile, cfg_counted, stats=st)
     counts = torch.tensor([st.rays, st.algorithmic_bytes()], dtype=torch.float64, device="cpu" if host_staged else "cuda")
-    if world > 1:
+    if dist_on:
         dist.all_reduce(counts)
     rays_total, _ = counts.tolist()
+    rays_total_rank0 = st.rays
     handoff = None
     if literal:
         cfg_counted.stack_mode = p3d.STACK_LITERAL
@@ -341,7 +350,7 @@ def main():
 
     # the same frames with the stack emptied at every primary sample (one launch per frame): N = 1 only
     per_pixel = None
-    if literal and world == 1:
+    if literal and not dist_on:
         cfg_pp = p3d.Config.from_buffer_copy(bytes(cfg))
         cfg_pp.stack_mode = p3d.STACK_PER_PIXEL
         pp_cold = p3d.Stats()
@@ -350,18 +359,21 @@ def main():
         render_into(bufs[0], tile, cfg_pp, stats=pp_cold, scene=fresh)
         for sc_, st_ in flight:
             render_into(bufs[0], tile, cfg_pp, stats=p3d.Stats(), scene=sc_, on=st_)
-        dt_pp = timed_loop(cfg_pp)
+        dts_pp = sorted(timed_loop(cfg_pp) for _ in range(TIMED_REPEATS))
+        dt_pp = dts_pp[len(dts_pp) // 2]
         pk = []
         for _ in range(16):
             st_ = p3d.Stats()
             render_into(bufs[0], tile, cfg_pp, stats=st_)
             pk.append(st_.kernel_ms)
         per_pixel = {"value": round(rays_total * args.steps / dt_pp / 1e6, 1), "ms_per_step": round(dt_pp / args.steps * 1e3, 4),
+                     "ms_per_step_repeats": [round(d / args.steps * 1e3, 4) for d in dts_pp],
                      "kernel_ms": round(sum(pk) / len(pk), 4), "cold_kernel_ms": round(pp_cold.kernel_ms, 4),
+                     "value_single_frame": round(rays_total / (sum(pk) / len(pk) * 1e-3) / 1e6, 1),
                      "note": "P3D_STACK_PER_PIXEL: hit IDs as the literal frame, colours within 1e-4 of it on this scene"}
 
     gather_check = None
-    if world > 1 and rank == 0:
+    if dist_on and rank == 0:
         # the last assembled frame must equal, bit for bit, what one GPU renders for the whole frame
         full = dev.full_tile()
         ref_pair = (torch.empty(p3d.packed_bytes(res * res), dtype=torch.uint8, device="cuda"),
@@ -398,11 +410,17 @@ def main():
         # The nearest ceiling (DESIGN.md "Measurement"): the scene is LDS- or L2-resident, so HBM serves the
         # framebuffer only.  What the dominant kernel spends is instruction issue: a wave64 VALU instruction takes its
         # SIMD-32 for 2 cycles, 1024 SIMDs at 2.4 GHz = 1228.8 G wave-instructions/s.  Instruction and HBM byte counts come from the rocprofv3 PMC passes
-        # of this workload committed under profiles/r02/ — quoted only if taken from exactly these kernel sources.
-        summary, src = pmc_summary(workload, args.stack_mode) if world == 1 else (None, "PMC summaries are per single-GPU workload")
+        # of this workload committed under profiles/r03/ — quoted only if taken from exactly these kernel sources.
+        summary, src = pmc_summary(workload, args.stack_mode) if not dist_on else (None, "PMC summaries are per single-GPU workload")
+        staged = os.path.getsize(scene_path) < 64 * 1024  # (the packaged small scenes: staged in LDS by the kernels)
         roof = {"kernel": dominant, "kernel_ms": round(dom_ms, 4),
                 "algorithmic": {"bytes_per_launch": int(alg_bytes_launch), "GBps": round(alg_gbps, 1),
-                                "note": "SURVEY.md 8(d) definition; served by LDS/L2, not by HBM, so not a fraction of anything"}}
+                                "frac_vs_hbm": round(alg_gbps / HBM_PEAK_GBPS, 4),
+                                "frac_vs_lds": round(alg_gbps / LDS_PEAK_GBPS, 4) if staged else None,
+                                "note": "SURVEY.md 8(d) definition: bytes the algorithm looks at / dominant kernel's duration.  They are served by "
+                                        "LDS (staged scenes) or L2 / Infinity Cache, not by HBM: frac_vs_hbm is NOT a bound when > 1 (nothing is "
+                                        "skipped: counters equal the oracle's query by query); frac_vs_lds prices them against the LDS "
+                                        "bandwidth of the chip (128 B/clk/CU); measured HBM traffic is under `traffic` / `hbm`"}}
         if summary:
             k = summary["dominant"]
             insts = k["SQ_INSTS_VALU"]
@@ -417,7 +435,7 @@ def main():
                          "rocprof_avg_ms": k.get("avg_ms"), "source": src,
                          "scope": "the dominant kernel of ONE frame on its own (kernel_ms live from HIP events, rocprof_avg_ms from "
                                   "the committed trace of `bench.py --frames-in-flight 1`)",
-                         "timed_loop_frac_lower_bound": round(insts / (dt / args.steps) / 1e9 / peak, 4) if world == 1 else None})
+                         "timed_loop_frac_lower_bound": round(insts / (dt / args.steps) / 1e9 / peak, 4) if not dist_on else None})
         else:
             roof.update({"bound": "valu_issue", "achieved": None, "peak": round(SIMDS * CLOCK_HZ / VALU_CYCLES / 1e9, 1), "unit": "Gwave-instr/s",
                          "frac": None, "traffic": None, "source": src})
@@ -425,6 +443,9 @@ def main():
             "metric": "Mrays/s (primary+secondary)", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "ms_per_step_repeats": [round(d / args.steps * 1e3, 4) for d in dts],
+            "value_single_frame": round(rays_total_rank0 / (kernel_ms * 1e-3) / 1e6, 1) if not dist_on else None,
+            "latency_ms_single_frame": round(kernel_ms, 4),
             "scaling": "strong" if fixed else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "resolution": [res, res], "rays_per_frame": int(rays_total),
@@ -439,7 +460,10 @@ def main():
                                          "; every frame's %s gathered to rank 0 over %s, %d frame(s) per collective, "
                                          "double-buffered; gathered frame vs single-GPU frame: %s"
                                          % ("u8 image" if gather == "u8" else "float RGB + hit IDs", "RCCL" if args.backend == "nccl" else "gloo (host-staged)", B, gather_check)
-                                         if world > 1 else "")},
+                                         if dist_on else "")},
+            "value_note": "value = throughput of the timed loop (median of %d repeats of exactly --steps steps) with `frames_in_flight` frames "
+                          "overlapping on as many device scenes and streams; value_single_frame / latency_ms_single_frame = ONE frame rendered "
+                          "alone (HIP events inside the library, mean of 16 frames)" % TIMED_REPEATS,
             "frame": {"kernel_ms": round(kernel_ms, 4), "pass1_ms": round(pass1_ms, 4), "handoff_ms": round(handoff_ms, 4),
                       "cold_kernel_ms": round(cold.kernel_ms, 4), "handoff": handoff,
                       "note": "ONE frame on its own: HIP events of the library on the launch stream (ms_per_step is the rate of the "
@@ -449,18 +473,18 @@ def main():
         }
         if per_pixel:
             out["per_pixel_stack"] = per_pixel
-        if world > 1:
+        if dist_on:
             single_gpu["value"] = round(rays_total / (single_gpu["ms_per_step"] * 1e-3) / 1e6, 1)
             out["single_gpu_same_workload"] = single_gpu
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not dist_on:
             out["cpu_baseline"] = cpu_baseline(workload, scene_path, cfg, res)
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
 def one_socket_cpus():
-    """CPUs of the socket this process may run on (affinity mask of the all-cores leg)."""
+    """Logical CPUs of one socket this process may run on, and how many physical cores they are."""
     allowed = sorted(os.sched_getaffinity(0))
     by_pkg = {}
     for c in allowed:
@@ -470,13 +494,31 @@ def one_socket_cpus():
             pkg = 0
         by_pkg.setdefault(pkg, []).append(c)
     pkg = min(by_pkg)
-    return pkg, by_pkg[pkg], len(by_pkg)
+    cores = set()
+    for c in by_pkg[pkg]:
+        try:
+            cores.add(int(open("/sys/devices/system/cpu/cpu%d/topology/core_id" % c).read()))
+        except OSError:
+            cores.add(c)
+    return pkg, by_pkg[pkg], len(by_pkg), len(cores)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(workload, scene_path, cfg, res):
-    """The oracle (CPU port of the reference's algorithm, literal semantics) on this host:
-    1 thread, as the reference is single-threaded.  Bounded sample: whole frames of the same
-    workload for cfg2 (about 1 s each), a centred crop for the heavier ones."""
+    """The oracle (CPU port of the reference's algorithm) on this host, bounded samples of the same workload:
+      * 1 thread, reference-literal semantics (the reference is single-threaded): repeated until 10 s of CPU work;
+      * every logical CPU of ONE socket, per-pixel stack (the serial stack cannot be threaded), rows handed out
+        dynamically, three runs of at least a second each (the tile repeated inside one thread pool), all three reported.
+    Whole frames for cfg1 / cfg2, a centred crop for the heavier workloads."""
     from oracle import binding as ob
     sc = ob.Scene(scene_path)
     sc.set_resolution(res, res)
@@ -496,34 +538,39 @@ def cpu_baseline(workload, scene_path, cfg, res):
         x0 = y0 = (res - w) // 2
         what = "renders of the centred %dx%d crop of the %dx%d frame" % (w, h, res, res)
     sc.render(ocfg, x0, y0, 8, 8)  # builds the BVH outside the timed region
-    # bounded sample: repeat until about 10 s of CPU work are done (at least 2, at most 64 repetitions), keep the best
-    best, rays, reps, spent = None, 0, 0, 0.0
-    while reps < 2 or (spent < 10.0 and reps < 64):
+    runs, rays, spent = [], 0, 0.0
+    while len(runs) < 3 or (spent < 10.0 and len(runs) < 64):
         _, _, st = sc.render(ocfg, x0, y0, w, h)
-        reps += 1
+        runs.append(st.seconds)
         spent += st.seconds
-        if best is None or st.seconds < best:
-            best, rays = st.seconds, st.rays
-    sample = "%d %s, %.1f s of CPU work, best one counted" % (reps, what, spent)
-    out = {"value": round(rays / best / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port", "sample": sample}
-    # all cores of ONE socket (rows dealt round-robin over that many threads, pinned to the socket; per-pixel stack —
-    # the reference's serial stack cannot be threaded), best of 3; informational
-    pkg, cpus, n_pkgs = one_socket_cpus()
+        rays = st.rays
+    runs.sort()
+    best, median = runs[0], runs[len(runs) // 2]
+    out = {"value": round(rays / median / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
+           "sample": "%d %s, %.1f s of CPU work, median counted (fastest run: %.3f Mrays/s)" % (len(runs), what, spent, rays / best / 1e6),
+           "semantics": "reference-literal: one hit_stack for the frame, zero-weight reflection rays traced", "cpu": cpu_model()}
+    pkg, cpus, n_pkgs, n_cores = one_socket_cpus()
     old = os.sched_getaffinity(0)
     try:
         os.sched_setaffinity(0, cpus)
         ocfg.stack_mode = 0
         ocfg.trace_zero_weight = 0
         ocfg.threads = len(cpus)
-        best = None
+        probe = sc.render_repeat(ocfg, 1, x0, y0, w, h)          # also warms the threads' code and data
+        repeat = max(1, int(math.ceil(1.5 / max(probe.seconds, 1e-4))))  # each run: at least about 1.5 s
+        socket_runs = []
         for _ in range(3):
-            _, _, st = sc.render(ocfg, x0, y0, w, h)
-            if best is None or st.seconds < best[0]:
-                best = (st.seconds, st.rays)
+            st = sc.render_repeat(ocfg, repeat, x0, y0, w, h)
+            socket_runs.append(st.rays / st.seconds / 1e6)
     finally:
         os.sched_setaffinity(0, old)
-    out["one_socket"] = {"value": round(best[1] / best[0] / 1e6, 3), "cores": len(cpus), "socket": pkg, "sockets_on_host": n_pkgs,
-                         "sample": "same sample, best of 3, threads pinned to the logical CPUs of one socket"}
+    socket_runs.sort()
+    out["one_socket"] = {"value": round(socket_runs[1], 3), "unit": "Mrays/s", "runs": [round(v, 3) for v in socket_runs],
+                         "spread": round((socket_runs[2] - socket_runs[0]) / socket_runs[1], 4),
+                         "cores": n_cores, "logical_cpus": len(cpus), "threads": len(cpus), "socket": pkg, "sockets_on_host": n_pkgs,
+                         "semantics": "per-pixel stack (P3D_STACK_PER_PIXEL semantics; the serial stack cannot be threaded)",
+                         "sample": "the same sample rendered %d times per run by one pool of %d threads pinned to the socket (rows handed out "
+                                   "dynamically), 3 runs of >= 1 s, median counted" % (repeat, len(cpus))}
     return out
 
 

@@ -217,6 +217,20 @@ class Scene:
                                items.ctypes.data_as(C.POINTER(C.c_uint32)))
         return dict(n=nxyz, bmin=mn, bmax=mx, cell_start=start, cell_items=items[:ni.value])
 
+    def render_repeat(self, cfg, repeat, x0=0, y0=0, w=None, h=None):
+        """The tile rendered `repeat` times by one thread pool (orc_render_repeat): timing runs. -> stats over all repetitions."""
+        rx, ry = self.resolution()
+        w = int(rx - x0 if w is None else w)
+        h = int(ry - y0 if h is None else h)
+        rgb = np.zeros((h, w, 3), np.float32)
+        hit = np.zeros((h, w), np.int32)
+        st = OrcStats()
+        rc = self._L.orc_render_repeat(self.h, C.byref(cfg), int(x0), int(y0), w, h, int(repeat), _fp(rgb),
+                                       hit.ctypes.data_as(C.POINTER(C.c_int32)), None, C.byref(st))
+        if rc != 0:
+            raise RuntimeError("orc_render_repeat failed rc=%d" % rc)
+        return st
+
     def render(self, cfg, x0=0, y0=0, w=None, h=None, want_rgb8=False):
         rx, ry = self.resolution()
         w = int(rx - x0 if w is None else w)

@@ -34,6 +34,7 @@
 #include "p3d_oracle.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -1357,9 +1358,14 @@ void rebuild_camera(Scene& S, int rx, int ry) {
              S.v_aperture, S.v_focal);
 }
 
-void render_rows(Ctx& cx, int x0, int y0, int w, int h, int row_first, int row_step, float* rgb,
-                 int32_t* hit, uint8_t* rgb8) {
-  for (int r = row_first; r < h; r += row_step) {
+// Rows are handed out one at a time from a shared counter (threads > 1: rows differ in cost by an order of magnitude,
+// and a fixed deal left the timing at the mercy of which thread got the expensive ones; the pixels do not depend on
+// who renders them: own RNG stream per pixel and sample, stack emptied per pixel in the threaded modes).
+void render_rows(Ctx& cx, int x0, int y0, int w, int h, std::atomic<int>& next_row, float* rgb,
+                 int32_t* hit, uint8_t* rgb8, int repeat = 1) {
+  const long long rows = (long long)h * repeat;  // timing runs render the tile `repeat` times with one thread pool
+  for (long long i = next_row.fetch_add(1, std::memory_order_relaxed); i < rows; i = next_row.fetch_add(1, std::memory_order_relaxed)) {
+    const int r = (int)(i % h);
     int y = y0 + r;
     for (int c = 0; c < w; c++) {
       size_t k = (size_t)r * w + c;
@@ -1578,7 +1584,14 @@ int orc_grid_cells(void* s, uint32_t* cell_start, uint32_t* cell_items) {
 
 int orc_render(void* s, const orc_config* cfg, int x0, int y0, int w, int h, float* rgb,
                int32_t* hit_id, uint8_t* rgb8, orc_stats* stats) {
+  return orc_render_repeat(s, cfg, x0, y0, w, h, 1, rgb, hit_id, rgb8, stats);
+}
+
+int orc_render_repeat(void* s, const orc_config* cfg, int x0, int y0, int w, int h, int repeat, float* rgb,
+                      int32_t* hit_id, uint8_t* rgb8, orc_stats* stats) {
   Scene* S = (Scene*)s;
+  if (repeat < 1) repeat = 1;
+  if (repeat > 1 && cfg->stack_mode != 0 && cfg->accel == 2) return -3;  // the serial stack would run on from frame to frame
   if (!S->has_cam) return -1;
   if (cfg->accel == 2) orc_build_bvh(s);
   if (cfg->accel == 1) orc_build_grid(s);
@@ -1594,12 +1607,13 @@ int orc_render(void* s, const orc_config* cfg, int x0, int y0, int w, int h, flo
     ctx[t].rng.mode = cfg->rng_mode;
   }
   if (cfg->rng_mode == 1) srand((unsigned)cfg->seed);  // maths.h:75-78
+  std::atomic<int> next_row(0);
   if (threads == 1) {
-    render_rows(ctx[0], x0, y0, w, h, 0, 1, rgb, hit_id, rgb8);
+    render_rows(ctx[0], x0, y0, w, h, next_row, rgb, hit_id, rgb8, repeat);
   } else {
     std::vector<std::thread> pool;
     for (int t = 0; t < threads; t++)
-      pool.emplace_back([&, t]() { render_rows(ctx[t], x0, y0, w, h, t, threads, rgb, hit_id, rgb8); });
+      pool.emplace_back([&, t]() { render_rows(ctx[t], x0, y0, w, h, next_row, rgb, hit_id, rgb8, repeat); });
     for (auto& th : pool) th.join();
   }
   auto t1 = std::chrono::high_resolution_clock::now();

@@ -92,6 +92,11 @@ int orc_grid_cells(void* s, uint32_t* cell_start, uint32_t* cell_items);
  * averaged colour before gamma; rgb8 after gamma + u8fromfloat.  Any output may be NULL. */
 int orc_render(void* s, const orc_config* cfg, int x0, int y0, int w, int h, float* rgb,
                int32_t* hit_id, uint8_t* rgb8, orc_stats* stats);
+/* The same tile rendered `repeat` times by ONE pool of cfg->threads threads (timing runs of bench.py's cpu_baseline:
+ * a sample long enough to time without paying for thread start-up per frame).  Counters and seconds cover all
+ * repetitions; not for the serial hit_stack (stack_mode 1 over the BVH), which would run on from frame to frame. */
+int orc_render_repeat(void* s, const orc_config* cfg, int x0, int y0, int w, int h, int repeat, float* rgb,
+                      int32_t* hit_id, uint8_t* rgb8, orc_stats* stats);
 
 /* unit-level entry points */
 int orc_aabb_intercepts(const float* bmin3, const float* bmax3, const float* o3, const float* d3,

@@ -13,6 +13,10 @@
 //                               (p3d_scene_create_device_bvh: same closest hits, shadow feelers may differ)
 //              [--skybox DIR]   DIR/{right,left,top,bottom,front,back}.ppm (binary P6; convert the
 //                               reference's JPEGs once with scenes/skybox_to_ppm.py) -> SKYBOX true
+//              [--gpus N]       the frame's rows dealt to N GPUs of this node in 8-row stripes (one device scene each, this
+//                               one process driving them), every GPU's part of the image brought to GPU 0 by ONE
+//                               ncclGather over xGMI (RCCL, loaded at run time), de-interleaved on the host.  Same image
+//                               as one GPU renders, bit for bit (P3D_STACK_LITERAL included: include/p3d.h, p3d_tile).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +26,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
 #include <zlib.h>
 
 #include "p3d.h"
@@ -97,13 +103,111 @@ bool load_ppm_face(const std::string& path, std::vector<uint8_t>& bytes, uint32_
   return true;
 }
 
+// ---- --gpus N: one process, N devices, one RCCL gather per frame (ncclGather, rccl.h:745) ----
+// RCCL is loaded with dlopen: a run without --gpus neither needs nor loads it.  Only the five entry points used here
+// are declared (types as in rccl.h: ncclComm_t is an opaque pointer, ncclResult_t / ncclDataType_t are enums; ncclUint8 = 1).
+struct Rccl {
+  void* lib = nullptr;
+  int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Gather)(const void* send, void* recv, size_t count, int datatype, int root, void* comm, hipStream_t stream) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load() {
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) { std::fprintf(stderr, "--gpus: cannot load librccl.so: %s\n", dlerror()); return false; }
+    auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) std::fprintf(stderr, "--gpus: librccl.so has no %s\n", n); return p; };
+    CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+    Gather = (decltype(Gather))sym("ncclGather");
+    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    return CommInitAll && CommDestroy && GroupStart && GroupEnd && Gather && GetErrorString;
+  }
+};
+constexpr int kNcclUint8 = 1;  // rccl.h: ncclUint8
+constexpr int kStripeRows = 8;
+
+// Renders the frame on n GPUs into `img` (bottom row first, 3 bytes per pixel).  Returns 0, or 1 after printing why not.
+int render_multi_gpu(const p3d_scene_desc* desc, bool device_bvh, p3d_config cfg, int n, std::vector<uint8_t>& img, double* secs) {
+  const int W = desc->camera.res_x, H = desc->camera.res_y;
+  int ndev = p3d_device_count();
+  if (n > ndev) { std::fprintf(stderr, "--gpus %d: this node shows %d HIP device(s)\n", n, ndev); return 1; }
+  if (H % (kStripeRows * n) != 0) { std::fprintf(stderr, "--gpus %d: the image height %d is not a multiple of %d rows\n", n, H, kStripeRows * n); return 1; }
+  Rccl rccl;
+  if (!rccl.load()) return 1;
+  auto hip_ok = [](hipError_t e, const char* what) { if (e != hipSuccess) std::fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e)); return e == hipSuccess; };
+  auto nccl_ok = [&](int r, const char* what) { if (r != 0) std::fprintf(stderr, "%s: %s\n", what, rccl.GetErrorString(r)); return r == 0; };
+  std::vector<int> devs(n);
+  for (int d = 0; d < n; ++d) devs[d] = d;
+  std::vector<void*> comms(n, nullptr);
+  if (!nccl_ok(rccl.CommInitAll(comms.data(), n, devs.data()), "ncclCommInitAll")) return 1;
+  const size_t part = (size_t)3 * W * (H / n);  // bytes of one GPU's stripes
+  std::vector<p3d_scene*> scenes(n, nullptr);
+  std::vector<hipStream_t> streams(n, nullptr);
+  std::vector<uint8_t*> d_part(n, nullptr);
+  uint8_t* d_all = nullptr;
+  cfg.collect_stats = 0;
+  for (int d = 0; d < n; ++d) {
+    const int rc = device_bvh && cfg.accel == P3D_ACCEL_BVH ? p3d_scene_create_device_bvh(desc, d, &scenes[d], nullptr) : p3d_scene_create(desc, d, &scenes[d]);
+    if (rc != P3D_OK) return die("scene_create");
+    if (!hip_ok(hipSetDevice(d), "hipSetDevice") || !hip_ok(hipStreamCreate(&streams[d]), "hipStreamCreate") ||
+        !hip_ok(hipMalloc((void**)&d_part[d], part), "hipMalloc"))
+      return 1;
+    if (d == 0 && !hip_ok(hipMalloc((void**)&d_all, part * n), "hipMalloc")) return 1;
+  }
+  auto frame = [&]() {
+    for (int d = 0; d < n; ++d) {  // every GPU renders its stripes: rows d*8 .. d*8+7, then every n-th stripe
+      p3d_tile t{0, d * kStripeRows, W, H / n, kStripeRows, n};
+      if (p3d_render_tile_device(scenes[d], &cfg, &t, nullptr, nullptr, d_part[d], streams[d], nullptr) != P3D_OK) return false;
+    }
+    if (!nccl_ok(rccl.GroupStart(), "ncclGroupStart")) return false;
+    for (int d = 0; d < n; ++d)
+      if (!nccl_ok(rccl.Gather(d_part[d], d == 0 ? d_all : nullptr, part, kNcclUint8, 0, comms[d], streams[d]), "ncclGather")) return false;
+    if (!nccl_ok(rccl.GroupEnd(), "ncclGroupEnd")) return false;
+    for (int d = 0; d < n; ++d)
+      if (!hip_ok(hipSetDevice(d), "hipSetDevice") || !hip_ok(hipStreamSynchronize(streams[d]), "hipStreamSynchronize")) return false;
+    return true;
+  };
+  if (!frame()) return 1;  // first frame: code objects loaded, tile schedules and halo chains recorded
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  if (!frame()) return 1;
+  *secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+  for (int d = 0; d < n; ++d)
+    if (p3d_scene_status(scenes[d]) != P3D_OK) return die("render");
+  std::vector<uint8_t> all(part * n);
+  if (!hip_ok(hipSetDevice(0), "hipSetDevice") || !hip_ok(hipMemcpy(all.data(), d_all, all.size(), hipMemcpyDeviceToHost), "hipMemcpy")) return 1;
+  // de-interleave: stripe k of GPU d holds frame rows (k * n + d) * 8 .. + 7
+  const size_t row_bytes = (size_t)3 * W;
+  for (int d = 0; d < n; ++d)
+    for (int r = 0; r < H / n; ++r) {
+      const int y = ((r / kStripeRows) * n + d) * kStripeRows + r % kStripeRows;
+      std::memcpy(&img[(size_t)y * row_bytes], &all[(size_t)d * part + (size_t)r * row_bytes], row_bytes);
+    }
+  for (int d = 0; d < n; ++d) {
+    (void)hipSetDevice(d);
+    (void)hipFree(d_part[d]);
+    (void)hipStreamDestroy(streams[d]);
+    p3d_scene_destroy(scenes[d]);
+    (void)rccl.CommDestroy(comms[d]);
+  }
+  (void)hipSetDevice(0);
+  (void)hipFree(d_all);
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
   p3d_config cfg;
   p3d_config_default(&cfg);
   std::string scene_path, skybox_dir, out = "RT_Output.png";  // main.cpp:851
-  int res_w = 0, res_h = 0, device = 0;
+  int res_w = 0, res_h = 0, device = 0, gpus = 0;
   bool device_bvh = false;
   uint32_t load_flags = 0;
   for (int i = 1; i < argc; ++i) {
@@ -132,6 +236,7 @@ int main(int argc, char** argv) {
     else if (a == "--stack") cfg.stack_mode = std::string(next("--stack")) == "per_pixel" ? P3D_STACK_PER_PIXEL : P3D_STACK_LITERAL;
     else if (a == "--device") device = std::atoi(next("--device"));
     else if (a == "--device-bvh") device_bvh = true;
+    else if (a == "--gpus") gpus = std::atoi(next("--gpus"));
     else if (a[0] != '-') scene_path = a;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
@@ -157,6 +262,20 @@ int main(int argc, char** argv) {
   if (p3d_host_scene_desc(hs, cfg.accel == P3D_ACCEL_BVH && !device_bvh, cfg.accel == P3D_ACCEL_GRID, &desc) != P3D_OK) return die("flatten");
   const int W = desc->camera.res_x, H = desc->camera.res_y;
   std::printf("\nResolutionX = %d  ResolutionY= %d.\n", W, H);  // main.cpp:986
+  if (gpus > 0) {  // several GPUs of this node (or one, through the same path): stripes + one RCCL gather
+    if (!skybox_dir.empty()) { std::fprintf(stderr, "--gpus with --skybox is not wired up in this front end\n"); return 2; }
+    std::vector<uint8_t> img((size_t)3 * W * H);
+    double secs = 0;
+    if (render_multi_gpu(desc, device_bvh, cfg, gpus, img, &secs)) return 1;
+    std::printf("Drawing finished!\n\nDone: %.2f (sec)\n", secs);
+    std::printf("%d GPU(s): stripes of %d rows, one ncclGather of %zu bytes per GPU; second frame %.3f ms (render + gather)\n", gpus, kStripeRows,
+                (size_t)3 * W * (H / gpus), secs * 1e3);
+    const bool ppm = out.size() > 4 && out.compare(out.size() - 4, 4, ".ppm") == 0;
+    if (!(ppm ? save_ppm(out, img, W, H) : save_png(out, img, W, H))) { std::printf("Error saving Image file\n"); return 1; }
+    std::printf("Image file created\n");
+    p3d_host_scene_destroy(hs);
+    return 0;
+  }
   p3d_scene* scene = nullptr;
   if (device_bvh && cfg.accel == P3D_ACCEL_BVH) {
     float build_ms = 0;

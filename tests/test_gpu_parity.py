@@ -688,6 +688,27 @@ def test_p3d_render_cli_writes_the_reference_image(tmp_path):
     assert (np.asarray(im)[::-1] == o8).all()
 
 
+def test_p3d_render_gpus_goes_through_rccl_and_writes_the_same_image(tmp_path):
+    """`p3d_render --gpus N`: the C++ front end deals the rows to N device scenes in 8-row stripes and brings every GPU's
+    part to GPU 0 with one ncclGather (RCCL loaded at run time), SURVEY.md 8(e).  This box has one GPU: N = 1 runs the
+    same code path (communicator, stripes with stripe_stride 1, gather, de-interleave) and must write the bytes of the
+    plain run; N = 2 must say why it cannot run here."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "p3d-raytracer_amd", "p3d_render")
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe), "p3d_render"])
+    common = [exe, scene_path("balls_low.p3f"), "--whitted", "--accel", "bvh", "--depth", "3", "--aa", "0", "--res", "160", "128"]
+    plain, multi = str(tmp_path / "plain.ppm"), str(tmp_path / "multi.ppm")
+    r = subprocess.run(common + ["--out", plain], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run(common + ["--out", multi, "--gpus", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ncclGather" in r.stdout and "Image file created" in r.stdout
+    assert open(plain, "rb").read() == open(multi, "rb").read()
+    r = subprocess.run(common + ["--out", multi, "--gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "HIP device" in r.stderr
+
+
 @pytest.mark.parametrize("accel", [p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH])
 def test_planes_boxes_and_glass(accel):
     """scenes/planes.p3f: `pl` objects (Plane::intercepts scene.cpp:116-137, default [-1,1]^3 bbox in
@@ -985,6 +1006,35 @@ def test_bench_contract_json_line():
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert cb["one_socket"]["cores"] >= 1 and cb["one_socket"]["value"] > 0
     assert d["value"] > 100 * cb["value"] and d["per_pixel_stack"]["value"] > d["value"]
+    # round 3: the single-frame figures next to the throughput, the repeats behind the median, the CPU runs behind theirs
+    assert len(d["ms_per_step_repeats"]) >= 5 and min(d["ms_per_step_repeats"]) <= d["ms_per_step"] <= max(d["ms_per_step_repeats"])
+    assert abs(d["latency_ms_single_frame"] - d["frame"]["kernel_ms"]) < 1e-9
+    assert abs(d["value_single_frame"] - 4944908 / (d["latency_ms_single_frame"] * 1e3)) < 0.01 * d["value_single_frame"]
+    assert rf["algorithmic"]["frac_vs_hbm"] > 0 and rf["algorithmic"]["frac_vs_lds"] is not None
+    assert len(cb["one_socket"]["runs"]) == 3 and cb["one_socket"]["cores"] <= cb["one_socket"]["logical_cpus"]
+
+
+def test_rccl_gather_path_runs_with_one_rank():
+    """The production collective - torch.distributed backend "nccl" = RCCL, device tensors, bench.py's double-buffered
+    send / finish / drain around p3d.gather_frame and p3d.assemble_frame - executed on this one-GPU box: `--force-dist`
+    takes the N > 1 path with a single rank, launched the way the driver launches ranks.  The assembled frame must equal
+    the frame rendered directly, bit for bit (bench.py checks and reports that itself)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    port = 31500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl",
+           "--workload", "tri100k", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 4
+    par = d["config"]["parallelism"]
+    assert "RCCL" in par and "gathered frame vs single-GPU frame: ok" in par, par
+    assert d["single_gpu_same_workload"]["value"] > 0 and d["value"] > 0
 
 
 def test_two_ranks_on_one_gpu_gather_the_single_gpu_frame():
