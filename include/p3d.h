@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define P3D_ABI_VERSION 2u
+#define P3D_ABI_VERSION 3u
 
 typedef enum p3d_status {
   P3D_OK = 0,
@@ -216,6 +216,13 @@ typedef struct p3d_scene_desc {
 #define P3D_CHAIN_MEGAKERNEL 1u
 #define P3D_CHAIN_PER_LEVEL 2u
 
+/* p3d_config.debug_view */
+#define P3D_DEBUG_NONE 0u
+#define P3D_DEBUG_TEST_INTERSECT 1u /* TEST_INTERSECT (constants.h:18): every hit is Color(1,0,0) (main.cpp:156, 359) */
+#define P3D_DEBUG_DEPTH_MAP 2u      /* DEPTH_MAP (constants.h:33): rayTracing without an acceleration structure returns
+                                       the grey value remap(5, 20, 1, 0, min_t), clamped (main.cpp:86-88, 127-139);
+                                       ignored with a grid or BVH and by the path tracer, as in the reference */
+
 typedef struct p3d_config {
   uint32_t integrator;    /* PATHTRACING        constants.h:36  */
   uint32_t accel;         /* acl_str            constants.h:44  */
@@ -236,6 +243,8 @@ typedef struct p3d_config {
                              every (pixel, sample) draws from its own stream */
   uint32_t stack_mode;    /* P3D_STACK_*: BVH::hit_stack across pixels (bvh.cpp:86) */
   uint32_t chain_launch;  /* P3D_CHAIN_*: how the reflect / refract chain is launched; never changes a result */
+  uint32_t debug_view;    /* P3D_DEBUG_*: the reference's two debug switches (constants.h:18,33), 0 as shipped */
+  uint32_t reserved0;
 } p3d_config;
 
 /*
@@ -428,8 +437,18 @@ int p3d_host_scene_desc(p3d_host_scene* hs, int build_bvh, int build_grid,
                         const p3d_scene_desc** out);
 /* Points the query methods of the host classes (C++: Object::intercepts / getNormal, BVH::intersect_bvh /
  * bool_intersect_bvh, Grid::Traverse, Scene::GetSkyboxColor — p3d-raytracer_amd/host/scene_model.hpp) at the
- * device scene created from this host scene's descriptor; they forward one query per call.  NULL unbinds. */
+ * device scene created from this host scene's descriptor, and uploads the cubemap the loader read for an `env`
+ * line (p3d_host_scene_has_skybox) to it.  NULL unbinds.
+ * The forwards exist so that code written against the reference's classes compiles and gives the reference's
+ * answers; each call is a kernel launch for ONE ray (about 10 us).  Anything that asks more than a handful of
+ * questions should ask them in one batch: p3d_trace_closest / p3d_trace_any / p3d_object_intercepts /
+ * p3d_object_normal / p3d_skybox_color take n rays per call. */
 int p3d_host_scene_bind_device(p3d_host_scene* hs, p3d_scene* scene);
+/* 1 if the `.p3f` had an `env <dir>` line (scene.cpp:605-610) and the six faces were found as binary PPMs
+ * (<dir>/{right,left,top,bottom,front,back}.ppm, relative to the working directory or to the scene file;
+ * scenes/skybox_to_ppm.py converts the reference's JPEG folder), 0 otherwise: JPEG decoding (DevIL in the
+ * reference) is not part of this library. */
+int p3d_host_scene_has_skybox(p3d_host_scene* hs);
 
 #ifdef __cplusplus
 }

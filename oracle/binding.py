@@ -22,7 +22,7 @@ class OrcConfig(C.Structure):
         ("light_side", C.c_float), ("gamma", C.c_float), ("skybox", C.c_int32),
         ("rng_mode", C.c_int32), ("stack_mode", C.c_int32), ("trace_zero_weight", C.c_int32),
         ("eval_order", C.c_int32), ("math_mode", C.c_int32), ("threads", C.c_int32),
-        ("seed", C.c_uint64),
+        ("debug_view", C.c_int32), ("seed", C.c_uint64),
     ]
 
 

@@ -913,7 +913,12 @@ C3 ray_tracing(Ctx& cx, Ray ray, int depth, float ior_1, int off_x, int off_y, b
   float min_t;
   int min_obj = closest_hit(cx, ray, min_t, hit_p);
   if (primary_hit) *primary_hit = min_obj;
+  if (cfg.accel == 0 && cfg.debug_view == 2) {  // DEPTH_MAP, main.cpp:127-139 (remap: main.cpp:86-88)
+    float depth_grey = 1.f + (min_t - 5.f) * (0.f - 1.f) / (20.f - 5.f);
+    return clamp(c3(depth_grey, depth_grey, depth_grey));
+  }
   if (min_obj < 0) return miss_color(S, cfg, ray);  // main.cpp:144-147
+  if (cfg.debug_view == 1) return c3(1, 0, 0);      // TEST_INTERSECT, main.cpp:156
 
   const Object& ob = S.objects[min_obj];
   const Material& mat = S.materials[ob.mat];
@@ -1039,6 +1044,7 @@ C3 radiance(Ctx& cx, Ray ray, int depth, float ior_1, int off_x, int off_y, bool
   int min_obj = closest_hit(cx, ray, min_t, hit_p);
   if (primary_hit) *primary_hit = min_obj;
   if (min_obj < 0 || depth == 0) return miss_color(S, cfg, ray);  // main.cpp:350-355
+  if (cfg.debug_view == 1) return c3(1, 0, 0);                    // TEST_INTERSECT, main.cpp:359
 
   const Object& ob = S.objects[min_obj];
   const Material& mat = S.materials[ob.mat];

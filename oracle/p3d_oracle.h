@@ -44,7 +44,8 @@ typedef struct orc_config {
                             bit3: reflection direction calls the left getDirection() first
                                   (main.cpp:293; both calls re-normalise the ray in place) */
   int32_t math_mode;     /* 0: detmath sin/cos (bit-identical to the HIP kernels); 1: host libm */
-  int32_t threads;       /* worker threads (rows dealt round-robin); needs rng_mode 0, stack_mode 0 */
+  int32_t threads;       /* worker threads (rows handed out dynamically); needs rng_mode 0, stack_mode 0 */
+  int32_t debug_view;    /* 0 none, 1 TEST_INTERSECT (main.cpp:156,359), 2 DEPTH_MAP (main.cpp:127-139, accel None only) */
   uint64_t seed;
 } orc_config;
 

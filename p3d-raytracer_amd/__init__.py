@@ -27,6 +27,7 @@ STACK_LITERAL, STACK_PER_PIXEL = 0, 1
 CHAIN_AUTO, CHAIN_MEGAKERNEL, CHAIN_PER_LEVEL = 0, 1, 2
 SAMPLE_JITTER, SAMPLE_TENT = 0, 1
 LOAD_LEGACY_F11 = 1
+DEBUG_NONE, DEBUG_TEST_INTERSECT, DEBUG_DEPTH_MAP = 0, 1, 2
 
 EXPORTS = [
     "p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_config_default",
@@ -34,7 +35,7 @@ EXPORTS = [
     "p3d_scene_status", "p3d_debug_set_trip_bound", "p3d_debug_set_max_rounds", "p3d_debug_set_halo_chain", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
     "p3d_trace_closest", "p3d_trace_any", "p3d_host_scene_load", "p3d_host_scene_destroy",
     "p3d_host_scene_set_resolution", "p3d_host_scene_set_lens", "p3d_host_scene_replicate_lights",
-    "p3d_host_scene_desc", "p3d_host_scene_bind_device",
+    "p3d_host_scene_desc", "p3d_host_scene_bind_device", "p3d_host_scene_has_skybox",
 ]
 
 
@@ -94,7 +95,7 @@ class Config(C.Structure):
                 ("sample_disk", C.c_uint32), ("soft_shadows", C.c_uint32), ("sample_mode", C.c_uint32),
                 ("light_side", C.c_float), ("gamma", C.c_float), ("collect_stats", C.c_uint32),
                 ("skybox", C.c_uint32), ("tile_order", C.c_uint32), ("seed", C.c_uint64),
-                ("stack_mode", C.c_uint32), ("chain_launch", C.c_uint32)]
+                ("stack_mode", C.c_uint32), ("chain_launch", C.c_uint32), ("debug_view", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class SkyboxFace(C.Structure):
@@ -165,6 +166,8 @@ def lib():
         L.p3d_host_scene_replicate_lights.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
         L.p3d_host_scene_desc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(SceneDesc))]
         L.p3d_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
+        L.p3d_host_scene_bind_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.p3d_host_scene_has_skybox.argtypes = [C.c_void_p]
         L.p3d_scene_destroy.argtypes = [C.c_void_p]
         L.p3d_scene_set_skybox.argtypes = [C.c_void_p, C.POINTER(SkyboxDesc)]
         L.p3d_render_tile.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(Tile), C.c_void_p, C.c_void_p,
@@ -249,6 +252,10 @@ class HostScene:
 
     def replicate_lights(self, spp_sqrt, light_side):
         _check(self._L.p3d_host_scene_replicate_lights(self._h, int(spp_sqrt), float(light_side)))
+
+    def has_skybox(self):
+        """The loader found the cubemap of the scene's `env` line as six binary PPM faces (p3d_host_scene_has_skybox)."""
+        return bool(self._L.p3d_host_scene_has_skybox(self._h))
 
     def desc(self, bvh=False, grid=False):
         p = C.POINTER(SceneDesc)()
@@ -340,6 +347,11 @@ class DeviceScene:
             d.face[i].img = f.ctypes.data
             d.face[i].res_x, d.face[i].res_y, d.face[i].bpp = f.shape[1], f.shape[0], f.shape[2]
         _check(self._L.p3d_scene_set_skybox(self._h, C.byref(d)))
+
+    def bind_host(self):
+        """p3d_host_scene_bind_device: the host classes' query forwards answer from this device scene, and the cubemap the
+        loader read for an `env` line is uploaded."""
+        _check(self._L.p3d_host_scene_bind_device(self.host._h, self._h))
 
     def full_tile(self):
         return Tile(0, 0, self.res[0], self.res[1], 0, 1)

@@ -85,6 +85,7 @@ struct RenderParams {
   uint32_t spp_sqrt, antialiasing, depth_of_field, sample_disk, soft_shadows, sample_mode;
   float light_side, gamma;
   uint32_t skybox;  // miss = cubemap texel (only set when the scene has a cubemap)
+  uint32_t debug_view;  // P3D_DEBUG_* (constants.h:18,33)
   uint64_t seed;
   // tile
   int32_t x0, y0, w, h, stripe_h, stripe_stride;

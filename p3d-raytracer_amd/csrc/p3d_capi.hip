@@ -666,6 +666,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   if (cfg->tile_order > P3D_TILE_ORDER_FRAME) return fail(P3D_ERR_INVALID, "bad tile_order");
   if (cfg->stack_mode > P3D_STACK_PER_PIXEL) return fail(P3D_ERR_INVALID, "bad stack_mode");
   if (cfg->chain_launch > P3D_CHAIN_PER_LEVEL) return fail(P3D_ERR_INVALID, "bad chain_launch");
+  if (cfg->debug_view > P3D_DEBUG_DEPTH_MAP) return fail(P3D_ERR_INVALID, "bad debug_view");
   if (cfg->max_depth < 0 || cfg->max_depth > 1024) return fail(P3D_ERR_INVALID, "max_depth out of range");
   if (cfg->antialiasing && (cfg->spp_sqrt == 0 || cfg->spp_sqrt > 1024)) return fail(P3D_ERR_INVALID, "spp_sqrt out of range");
   if (cfg->soft_shadows && !cfg->antialiasing)
@@ -713,6 +714,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   P.depth_of_field = cfg->depth_of_field; P.sample_disk = cfg->sample_disk; P.soft_shadows = cfg->soft_shadows;
   P.sample_mode = cfg->sample_mode; P.light_side = cfg->light_side; P.gamma = cfg->gamma; P.seed = cfg->seed;
   P.skybox = cfg->skybox ? 1u : 0u;
+  P.debug_view = cfg->debug_view;
   P.stripe_h = tile->stripe_h > 0 ? tile->stripe_h : 0; P.stripe_stride = ss;
   P.stats = s->d_stats;
   P.status = s->d_status;

@@ -237,6 +237,11 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
         alive = false;
         continue;
       }
+      if (P.debug_view == P3D_DEBUG_TEST_INTERSECT) {  // main.cpp:359
+        L = L + T * f3(1, 0, 0);
+        alive = false;
+        continue;
+      }
       ct.add(kShadedHits);
       const uint32_t m = geom_material(g);
       const float4 m0 = sc.mats[4 * m], m1 = sc.mats[4 * m + 1], m2 = sc.mats[4 * m + 2], m3 = sc.mats[4 * m + 3];

@@ -173,6 +173,8 @@ int p3d_host_scene_desc(p3d_host_scene* hs, int build_bvh, int build_grid, const
   return P3D_OK;
 }
 
+int p3d_host_scene_has_skybox(p3d_host_scene* hs) { return hs && hs->scene.SkyboxLoaded() ? 1 : 0; }
+
 int p3d_host_scene_bind_device(p3d_host_scene* hs, p3d_scene* scene) {
   if (!hs) return p3d::fail(P3D_ERR_INVALID, "p3d_host_scene_bind_device: null argument");
   if (hs->bvh) hs->bvh->bindDevice(scene);

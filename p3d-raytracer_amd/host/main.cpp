@@ -284,6 +284,10 @@ int main(int argc, char** argv) {
   } else if (p3d_scene_create(desc, device, &scene) != P3D_OK) {
     return die("scene_create");
   }
+  if (skybox_dir.empty() && p3d_host_scene_has_skybox(hs)) {  // `env <dir>` in the scene file, faces found as PPMs: SKYBOX true (constants.h:30)
+    if (p3d_host_scene_bind_device(hs, scene) != P3D_OK) return die("skybox");
+    cfg.skybox = 1;
+  }
   if (!skybox_dir.empty()) {  // Scene::LoadSkybox (scene.cpp:329-377) + SKYBOX true (constants.h:30)
     static const char* names[6] = {"right", "left", "top", "bottom", "front", "back"};
     std::vector<uint8_t> bytes[6];

@@ -217,7 +217,7 @@ bool Scene::load_p3f(const char* name, bool legacy_f11) {
   if (!in.is_open()) return false;
 
   Material* current = nullptr;
-  bool stop = false;
+  bool stop = false, env_failed = false;
 
   auto keyword = [&](const char* expect) {  // scene.cpp:465-470: mismatch only warns
     std::string tok;
@@ -305,9 +305,23 @@ bool Scene::load_p3f(const char* name, bool legacy_f11) {
          in >> c;
          SetBackgroundColor(c);
        }},
-      {"env", [&] {  // the six cubemap JPEGs are not loaded: miss shading uses bclr (SKYBOX false)
-         in >> skyboxDir;
+      {"env", [&] {  // scene.cpp:605-610: LoadSkybox(<dir>) + SetSkyBoxFlg(true)
+         // The reference decodes <dir>/*.jpg through DevIL and exits if a face is missing.  This library decodes nothing:
+         // the faces are loaded when the folder holds them as binary PPMs (scenes/skybox_to_ppm.py), looked up relative
+         // to the working directory as the reference does and, failing that, next to the scene file; with no PPM folder
+         // the directory is only recorded (GetSkyboxDir) and a later LoadSkybox / p3d_scene_set_skybox supplies the faces.
+         std::string dir;
+         in >> dir;
+         skyboxDir = dir;
          SetSkyBoxFlg(true);
+         std::string beside = name;
+         const size_t slash = beside.find_last_of('/');
+         beside = slash == std::string::npos ? dir : beside.substr(0, slash + 1) + dir;
+         for (const std::string& cand : {dir, beside}) {
+           if (!std::ifstream(cand + "/right.ppm", std::ios::binary).is_open()) continue;
+           if (!LoadSkybox(cand.c_str())) stop = env_failed = true;  // faces present but unreadable: the reference would exit(0) here
+           break;
+         }
        }},
   };
 
@@ -323,7 +337,7 @@ bool Scene::load_p3f(const char* name, bool legacy_f11) {
       break;
     }
   }
-  return true;
+  return !env_failed;
 }
 
 }  // namespace p3d

@@ -245,6 +245,7 @@ class Scene {
   // DevIL; this library has no image decoder: the faces are read as binary PPMs (scenes/skybox_to_ppm.py converts a
   // folder once) and kept bottom row first (IL_ORIGIN_LOWER_LEFT).  Uploaded to the bound device scene, now or at bindDevice.
   bool LoadSkybox(const char* sky_dir);
+  bool SkyboxLoaded() const { return skybox_loaded; }
   Color GetSkyboxColor(Ray& r);  // scene.cpp:379-457, one lookup on the device (p3d_skybox_color)
   // The device scene that answers the ray queries of this scene's objects (p3d_scene_create of this scene's
   // descriptor).  Not owned.  nullptr unbinds.

@@ -36,7 +36,7 @@ def oracle_cfg_like(cfg, **kw):
     base = dict(integrator=cfg.integrator, accel=cfg.accel, max_depth=cfg.max_depth, spp_sqrt=cfg.spp_sqrt,
                 antialiasing=cfg.antialiasing, depth_of_field=cfg.depth_of_field, sample_disk=cfg.sample_disk,
                 soft_shadows=cfg.soft_shadows, sample_mode=cfg.sample_mode, light_side=cfg.light_side,
-                gamma=cfg.gamma, skybox=cfg.skybox, seed=cfg.seed, rng_mode=0, stack_mode=1 if lit else 0,
+                gamma=cfg.gamma, skybox=cfg.skybox, seed=cfg.seed, debug_view=cfg.debug_view, rng_mode=0, stack_mode=1 if lit else 0,
                 trace_zero_weight=1 if lit else 0, math_mode=0, threads=1 if lit else 8)
     base.update(kw)
     return ob.default_config(**base)
@@ -780,6 +780,69 @@ def test_skybox_miss_shading(scene, integrator, accel):
     # and the switch is really a switch
     plain, _, _ = dev.render(p3d.whitted_config(accel=accel, max_depth=3, skybox=0))
     assert np.abs(plain - rgb).max() > 0.05
+
+
+def _write_ppm_faces(folder, faces):
+    os.makedirs(folder, exist_ok=True)
+    for name, f in zip(p3d.SKYBOX_FACE_FILES, faces):  # file rows are top-down, the faces are kept bottom row first
+        rgb = np.ascontiguousarray(f[::-1, :, :3])
+        with open(os.path.join(folder, name + ".ppm"), "wb") as out:
+            out.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]))
+            out.write(rgb.tobytes())
+
+
+def test_env_line_loads_the_cubemap_when_the_faces_are_there(tmp_path):
+    """`env <dir>` (scene.cpp:605-610: LoadSkybox + SetSkyBoxFlg): the loader reads the six faces when the folder holds
+    them as binary PPMs (JPEG decoding is DevIL's job in the reference and nobody's here), next to the scene file or in the
+    working directory; binding the host scene to the device scene uploads them.  Same frame as handing the faces over
+    through p3d_scene_set_skybox; without the folder the scene still loads and has no cubemap."""
+    faces = _synthetic_skybox()
+    src = open(scene_path("balls_low.p3f")).read()
+    assert "env skybox" in src  # the packaged scenes all name the reference's JPEG folder
+    scene = tmp_path / "with_env.p3f"
+    scene.write_text(src.replace("env skybox", "env sky_ppm"))
+    hs_none = p3d.HostScene(str(scene))
+    assert not hs_none.has_skybox()
+    _write_ppm_faces(str(tmp_path / "sky_ppm"), faces)
+    hs = p3d.HostScene(str(scene))
+    assert hs.has_skybox()
+    hs.set_resolution(96, 96)
+    dev = p3d.DeviceScene(hs, bvh=True)
+    cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=3, skybox=1)
+    with pytest.raises(p3d.P3DError):
+        dev.render(cfg)           # no cubemap on the device yet
+    dev.bind_host()
+    rgb, hit, _ = dev.render(cfg)
+    ref = p3d.DeviceScene(hs, bvh=True)
+    ref.set_skybox([f[:, :, :3] for f in faces])
+    want, want_hit, _ = ref.render(cfg)
+    assert (rgb.view(np.uint32) == want.view(np.uint32)).all() and (hit == want_hit).all()
+
+
+@pytest.mark.parametrize("accel", [p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH])
+def test_debug_views_of_constants_h(accel):
+    """TEST_INTERSECT (constants.h:18: every hit is Color(1,0,0), main.cpp:156 and :359) and DEPTH_MAP (constants.h:33:
+    grey = remap(5, 20, 1, 0, min_t) clamped, only without an acceleration structure, main.cpp:127-139) as
+    p3d_config.debug_view: bit-identical to the oracle, for rayTracing and (TEST_INTERSECT) for the path tracer."""
+    dev, sc = _pair(scene_path("balls_low.p3f"), res=(96, 96))
+    for view in (p3d.DEBUG_TEST_INTERSECT, p3d.DEBUG_DEPTH_MAP):
+        cfg = p3d.whitted_config(accel=accel, max_depth=3, debug_view=view, collect_stats=1)
+        rgb, hit, st = dev.render(cfg)
+        o_rgb, o_hit, o_st = sc.render(oracle_cfg_like(cfg))
+        assert_bit_identical((rgb, hit), (o_rgb, o_hit), "debug view %d" % view)
+        assert st.rays == o_st.rays and st.shaded_hits == o_st.shaded_hits
+        if view == p3d.DEBUG_TEST_INTERSECT:
+            assert (rgb[hit >= 0] == np.array([1, 0, 0], np.float32)).all() and st.rays == 96 * 96 and st.shaded_hits == 0
+        elif accel == p3d.ACCEL_NONE:
+            assert (rgb[..., 0] == rgb[..., 1]).all() and (rgb[hit < 0] == 0).all() and 0 < rgb.max() <= 1 and st.rays == 96 * 96
+        else:  # DEPTH_MAP does nothing with a grid or BVH: the ordinary frame
+            plain, _, _ = dev.render(p3d.whitted_config(accel=accel, max_depth=3))
+            assert (plain.view(np.uint32) == rgb.view(np.uint32)).all()
+    pt = p3d.pathtrace_config(accel=accel, spp_sqrt=3, max_depth=8, seed=5, debug_view=p3d.DEBUG_TEST_INTERSECT)
+    dev2, sc2 = _pair(scene_path("path_balls.p3f"), res=(64, 64))
+    rgb, hit, _ = dev2.render(pt)
+    o_rgb, o_hit, _ = sc2.render(oracle_cfg_like(pt))
+    assert (hit == o_hit).all() and np.abs(rgb - o_rgb).max() <= 1e-6
 
 
 def test_shipped_cubemap_skybox():

@@ -27,13 +27,13 @@ def test_library_exports_every_declared_symbol():
     lib = p3d.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.p3d_abi_version() == 2
+    assert lib.p3d_abi_version() == 3  # round 3: p3d_config.debug_view
 
 
 def test_struct_layouts_match_the_header():
     assert C.sizeof(p3d.Prim) == 96 and C.sizeof(p3d.Material) == 64 and C.sizeof(p3d.Light) == 32
     assert C.sizeof(p3d.Camera) == 80 and C.sizeof(p3d.BvhNode) == 32
-    assert C.sizeof(p3d.Config) == 72 and C.sizeof(p3d.Tile) == 24 and C.sizeof(p3d.Stats) == 20 * 8
+    assert C.sizeof(p3d.Config) == 80 and C.sizeof(p3d.Tile) == 24 and C.sizeof(p3d.Stats) == 20 * 8
 
 
 def test_config_default_is_constants_h():
@@ -42,6 +42,7 @@ def test_config_default_is_constants_h():
     assert (c.antialiasing, c.depth_of_field, c.sample_disk, c.soft_shadows, c.sample_mode) == (1, 1, 1, 0, 0)
     assert (c.light_side, c.gamma) == (0.5, 1.0)
     assert c.stack_mode == p3d.STACK_LITERAL  # one hit_stack for the whole frame (bvh.cpp:86)
+    assert c.debug_view == p3d.DEBUG_NONE     # TEST_INTERSECT false, DEPTH_MAP false (constants.h:18,33)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
