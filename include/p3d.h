@@ -216,6 +216,14 @@ typedef struct p3d_scene_desc {
 #define P3D_CHAIN_MEGAKERNEL 1u
 #define P3D_CHAIN_PER_LEVEL 2u
 
+/* p3d_config.handoff_records.  COMPACT (default): leftovers share a pool of 8 entries (64 bytes) per pixel of the tile on
+ * average - most pixels leave nothing, a few leave up to lights x tree depth entries; a frame that needs more fails with
+ * P3D_ERR_CAPACITY (the host-buffer call p3d_render_tile then renders it again with DENSE records by itself; after a
+ * device-buffer call ask p3d_scene_status and repeat the call with DENSE).  DENSE: room for the worst case of every pixel
+ * (2 x lights x tree depth x 8 bytes per pixel: 2.7 GB for the 100k-triangle frame at 2048 x 2048), cannot run out. */
+#define P3D_HANDOFF_COMPACT 0u
+#define P3D_HANDOFF_DENSE 1u
+
 /* p3d_config.debug_view */
 #define P3D_DEBUG_NONE 0u
 #define P3D_DEBUG_TEST_INTERSECT 1u /* TEST_INTERSECT (constants.h:18): every hit is Color(1,0,0) (main.cpp:156, 359) */
@@ -244,7 +252,7 @@ typedef struct p3d_config {
   uint32_t stack_mode;    /* P3D_STACK_*: BVH::hit_stack across pixels (bvh.cpp:86) */
   uint32_t chain_launch;  /* P3D_CHAIN_*: how the reflect / refract chain is launched; never changes a result */
   uint32_t debug_view;    /* P3D_DEBUG_*: the reference's two debug switches (constants.h:18,33), 0 as shipped */
-  uint32_t reserved0;
+  uint32_t handoff_records; /* P3D_HANDOFF_*: storage of the per-pixel hit_stack leftovers under P3D_STACK_LITERAL; never changes a result */
 } p3d_config;
 
 /*
@@ -379,6 +387,9 @@ int p3d_debug_set_max_rounds(uint32_t rounds);
 /* Test hook: how many frame pixels the search in front of a row of a stripe / sub-rectangle may collect before it has to
  * find one whose leftover provably does not depend on its own incoming hit_stack (0 = the real bound, 16), process-wide. */
 int p3d_debug_set_halo_chain(uint32_t pixels);
+/* Test hook: size of the pool of the COMPACT hit_stack leftover records in entries (0 = the real rule: 8 per pixel of the
+ * tile, at least 65536), process-wide. */
+int p3d_debug_set_leftover_pool(uint32_t entries);
 
 /*
  * Batched traversal queries — device counterparts of BVH::intersect_bvh

@@ -28,11 +28,12 @@ CHAIN_AUTO, CHAIN_MEGAKERNEL, CHAIN_PER_LEVEL = 0, 1, 2
 SAMPLE_JITTER, SAMPLE_TENT = 0, 1
 LOAD_LEGACY_F11 = 1
 DEBUG_NONE, DEBUG_TEST_INTERSECT, DEBUG_DEPTH_MAP = 0, 1, 2
+HANDOFF_COMPACT, HANDOFF_DENSE = 0, 1
 
 EXPORTS = [
     "p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_config_default",
     "p3d_scene_create", "p3d_scene_create_device_bvh", "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_render_tile", "p3d_render_tile_device",
-    "p3d_scene_status", "p3d_debug_set_trip_bound", "p3d_debug_set_max_rounds", "p3d_debug_set_halo_chain", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
+    "p3d_scene_status", "p3d_debug_set_trip_bound", "p3d_debug_set_max_rounds", "p3d_debug_set_halo_chain", "p3d_debug_set_leftover_pool", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
     "p3d_trace_closest", "p3d_trace_any", "p3d_host_scene_load", "p3d_host_scene_destroy",
     "p3d_host_scene_set_resolution", "p3d_host_scene_set_lens", "p3d_host_scene_replicate_lights",
     "p3d_host_scene_desc", "p3d_host_scene_bind_device", "p3d_host_scene_has_skybox",
@@ -95,7 +96,7 @@ class Config(C.Structure):
                 ("sample_disk", C.c_uint32), ("soft_shadows", C.c_uint32), ("sample_mode", C.c_uint32),
                 ("light_side", C.c_float), ("gamma", C.c_float), ("collect_stats", C.c_uint32),
                 ("skybox", C.c_uint32), ("tile_order", C.c_uint32), ("seed", C.c_uint64),
-                ("stack_mode", C.c_uint32), ("chain_launch", C.c_uint32), ("debug_view", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("stack_mode", C.c_uint32), ("chain_launch", C.c_uint32), ("debug_view", C.c_uint32), ("handoff_records", C.c_uint32)]
 
 
 class SkyboxFace(C.Structure):
@@ -184,6 +185,7 @@ def lib():
         L.p3d_debug_set_trip_bound.argtypes = [C.c_uint32]
         L.p3d_debug_set_max_rounds.argtypes = [C.c_uint32]
         L.p3d_debug_set_halo_chain.argtypes = [C.c_uint32]
+        L.p3d_debug_set_leftover_pool.argtypes = [C.c_uint32]
         _lib = L
     return _lib
 

@@ -32,8 +32,8 @@ constexpr uint32_t kHaloChain = 16;       // slots in front of a row that starts
 constexpr uint32_t kMetaTouched = 1u << 17;
 constexpr uint32_t kNoUnit = 0xffffffffu;
 
-enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoUnused, kHoListA, kHoListB, kHoListC, kHoListD, kHoNumCounters };
-constexpr uint32_t kHoErrLeftoverCap = 1u;   // a leftover had more entries than a slot holds
+enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoPoolTop, kHoListA, kHoListB, kHoListC, kHoListD, kHoNumCounters };
+constexpr uint32_t kHoErrLeftoverCap = 1u;   // a leftover had more entries than a slot holds, or the leftover pool is full
 constexpr uint32_t kHoErrNoFixedPoint = 2u;  // round bound reached
 constexpr uint32_t kHoErrTrips = 4u;         // sample hand-out loop hit its trip bound (SUB = 4 kernels)
 constexpr uint32_t kHoErrList = 8u;          // a work list or a ray queue segment overflowed
@@ -51,7 +51,15 @@ struct Handoff {
   uint32_t round_base;  // rounds that came before this launch
   uint32_t count;       // keep the checked / redone statistics (one contended atomic per wave: only on request)
   uint32_t lanes;       // list kernel: list entries per wave (fewer = less divergence between unrelated pixels)
-  uint2* entries;          // [2][cap][n_units]  leftover stacks, two slots per unit
+  // Leftover stacks, two slots per unit (a unit rendered again writes its other slot: nothing is read while it is written).
+  // Compact (default): `entries` is a pool, a leftover of n entries takes n consecutive ones from a bump pointer (one atomic
+  // per wave) and where[slot][unit] says where - most units leave nothing, the worst case is cap entries (lights x tree depth).
+  // Dense (per-level launches, p3d_config.handoff_records = P3D_HANDOFF_DENSE): slot s of unit u at (s * n_units + u) * cap.
+  uint2* entries;
+  uint32_t* where;         // compact: [2][n_units] first pool entry of the slot
+  uint32_t* pool_top;      // compact: next free pool entry
+  uint32_t pool_cap;       // entries in the pool
+  uint32_t dense;
   uint32_t* meta;          // [n_units] bits 0..15 entries of the current slot, bit 16 which slot, bit 17 touched
   float4* first;           // [n_units] {hit point, object id} of the first closest hit of the first touching sample
   uint32_t* first_sample;  // [n_units] index of that sample (anti-aliased launches)
@@ -125,6 +133,33 @@ __host__ __device__ inline int handoff_succ(const Handoff& H, uint32_t u) {
     if (row >= H.rows || H.row_chain[row]) return -1;
     i = hi;
   }
+}
+
+__device__ __forceinline__ uint32_t leftover_at(const Handoff& H, uint32_t slot, uint32_t unit) {
+  return H.dense ? (slot * H.n_units + unit) * H.cap : H.where[slot * H.n_units + unit];
+}
+// Room for the n entries a lane wants to leave in `slot` of `unit` (n = 0: none).  EVERY lane of the wave has to call this
+// together (wave prefix sum, one atomic per wave).  Returns the first entry, kNoUnit if the pool is full (status raised).
+__device__ __forceinline__ uint32_t leftover_alloc(const Handoff& H, uint32_t n, uint32_t slot, uint32_t unit, uint32_t* status) {
+  if (H.dense) return (slot * H.n_units + unit) * H.cap;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t incl = n;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o, 64);
+    if ((int)lane >= o) incl += v;
+  }
+  const uint32_t total = __shfl(incl, 63, 64);
+  uint32_t base = 0;
+  if (lane == 63 && total) base = atomicAdd(H.pool_top, total);
+  base = __shfl(base, 63, 64);
+  const uint32_t at = base + incl - n;
+  if (n == 0) return kNoUnit;
+  if ((unsigned long long)at + n > H.pool_cap) {
+    atomicOr(status, kHoErrLeftoverCap);
+    return kNoUnit;
+  }
+  H.where[slot * H.n_units + unit] = at;
+  return at;
 }
 
 __device__ __forceinline__ bool handoff_touched(const Handoff& H, uint32_t u) { return (H.touched[u >> 5] >> (u & 31u)) & 1u; }

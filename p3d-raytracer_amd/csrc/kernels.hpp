@@ -353,8 +353,9 @@ template <bool SPILL, class CT>
 __device__ __forceinline__ void seed_stack(Stack& st, const Handoff& H, uint32_t pred, uint32_t slot_count, CT& ct) {
   stack_clear(st);
   const uint32_t n = slot_count & 0xffffu, slot = slot_count >> 16;
+  const uint32_t at = n ? leftover_at(H, slot, pred) : 0u;
   for (uint32_t e = 0; e < n; ++e) {
-    const uint2 v = H.entries[((size_t)slot * H.cap + e) * H.n_units + pred];
+    const uint2 v = H.entries[at + e];
     push<SPILL>(st, v.x, __uint_as_float(v.y), ct);
   }
 }
@@ -548,6 +549,8 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
         if (active && H.count) atomicAdd(&H.counters[kHoRedone], 1u);
       }
       if (LIT == 1) stack_clear(st);
+      uint32_t leave_n = 0, leave_slot = 0;  // LIT != 0: entries this lane's unit leaves, stored after the lanes have come together again
+      bool leave_succ = false;
 
       if (active) {
         const int c = up.c, r = up.r, x = up.x, y = up.y;
@@ -657,7 +660,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
           if (unit_touched) {
             uint32_t n = (uint32_t)st.sp;
             if (n > H.cap) { atomicOr(P.status, kHoErrLeftoverCap); n = H.cap; }
-            for (uint32_t e = 0; e < n; ++e) H.entries[(size_t)e * H.n_units + unit] = stack_read<SPILL>(st, (int)e);
+            leave_n = n;
             meta = n | kMetaTouched;
             H.first[unit] = unit_first;
             if (AA) H.first_sample[unit] = unit_first_sample;
@@ -675,18 +678,31 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
           uint32_t n = (uint32_t)st.sp;
           if (n > H.cap) { atomicOr(P.status, kHoErrLeftoverCap); n = H.cap; }
           bool same = n == cnt;
+          const uint32_t old_at = (same && n) ? leftover_at(H, cur, unit) : 0u;
           for (uint32_t e = 0; same && e < n; ++e) {
-            const uint2 a = H.entries[((size_t)cur * H.cap + e) * H.n_units + unit], b = stack_read<SPILL>(st, (int)e);
+            const uint2 a = H.entries[old_at + e], b = stack_read<SPILL>(st, (int)e);
             same = a.x == b.x && a.y == b.y;
           }
           H.first[unit] = unit_first;
           if (!same) {
-            const uint32_t nb = cur ^ 1u;
-            for (uint32_t e = 0; e < n; ++e) H.entries[((size_t)nb * H.cap + e) * H.n_units + unit] = stack_read<SPILL>(st, (int)e);
-            H.meta[unit] = n | (nb << 16) | kMetaTouched;
-            const int succ = handoff_succ(H, unit);
-            if (succ >= 0) handoff_append(list_out, n_out_p, H.list_cap, P.status, make_uint4((uint32_t)succ, unit, (nb << 16) | n, 1u));
+            leave_n = n;
+            leave_slot = cur ^ 1u;
+            leave_succ = true;
+            H.meta[unit] = n | (leave_slot << 16) | kMetaTouched;
           }
+        }
+      }
+      if (LIT != 0) {  // every lane: room in the leftover pool (one atomic per wave), then the entries
+        const uint32_t at = leftover_alloc(H, leave_n, leave_slot, unit, P.status);
+        if (at != kNoUnit) {
+          for (uint32_t e = 0; e < leave_n; ++e) H.entries[at + e] = stack_read<SPILL>(st, (int)e);
+        } else if (leave_n) {  // pool full: the call fails (status); the records must still not point anywhere
+          leave_n = 0;
+          H.meta[unit] = (leave_slot << 16) | kMetaTouched;
+        }
+        if (LIT == 2 && leave_succ) {
+          const int succ = handoff_succ(H, unit);
+          if (succ >= 0) handoff_append(list_out, n_out_p, H.list_cap, P.status, make_uint4((uint32_t)succ, unit, (leave_slot << 16) | leave_n, 1u));
         }
       }
       if (LIT != 2) break;

@@ -101,6 +101,8 @@ inline uint32_t redo_lanes() {
 uint32_t g_debug_trip_bound = 0;  // tests: force the sample hand-out loops of the SUB = 4 kernels to give up early
 uint32_t g_debug_max_rounds = 0;  // tests: round bound of the hit_stack hand-off (0 = the real one)
 uint32_t g_debug_halo_chain = 0;  // tests: pixels halo_find_kernel may collect in front of a row (0 = kHaloChain)
+constexpr uint32_t kPoolEntriesPerUnit = 8;  // compact hand-off records: pool entries per unit of the tile
+uint32_t g_debug_pool_entries = 0;           // tests: the whole pool (0 = the real rule)
 
 // Tile of a wave of the one-lane-per-pixel Whitted kernels over a scene traversed from L2 (see p3d_render_tile_device).
 // P3D_TILE_SHAPE = 88 | 84 | 44 in the environment overrides the rule (experiments).
@@ -135,7 +137,7 @@ struct p3d_scene {
   float device_bvh_ms = 0;  // GPU time of lbvh::build, 0 for an uploaded tree
   Scratch levels, spill, deferred, wf_rays, wf_keys, wf_sorted, wf_final, out_rgb, out_hit, out_rgb8, q_in, q_out;
   // P3D_STACK_LITERAL (csrc/handoff.hpp): leftovers, per-unit records, work lists, counters
-  Scratch ho_entries, ho_meta, ho_first, ho_first_sample, ho_touched, ho_lists, ho_counters, ho_row_chain, ho_halo_pix, ho_ucount;
+  Scratch ho_where, ho_entries, ho_meta, ho_first, ho_first_sample, ho_touched, ho_lists, ho_counters, ho_row_chain, ho_halo_pix, ho_ucount;
   std::vector<int64_t> ho_chain_key;     // what the row_chain flags and halo pixels on the device were worked out for
   bool has_spheres = false;              // (halo_find_kernel: only a sphere test re-normalises a ray)
   uint32_t* d_halo_verdict = nullptr;    // kHoErrHalo if the memoised halo search could not start some row exactly
@@ -170,7 +172,7 @@ void p3d_scene_destroy(p3d_scene* s) {
     if (e.ready) (void)hipEventDestroy(e.ready);
   }
   s->levels.release(); s->spill.release(); s->deferred.release(); s->wf_rays.release(); s->wf_keys.release(); s->wf_sorted.release(); s->wf_final.release(); s->out_rgb.release(); s->out_hit.release();
-  s->ho_entries.release(); s->ho_meta.release(); s->ho_first.release(); s->ho_first_sample.release(); s->ho_touched.release();
+  s->ho_where.release(); s->ho_entries.release(); s->ho_meta.release(); s->ho_first.release(); s->ho_first_sample.release(); s->ho_touched.release();
   s->ho_lists.release(); s->ho_counters.release(); s->ho_row_chain.release(); s->ho_halo_pix.release(); s->ho_ucount.release();
   if (s->d_status) (void)hipFree(s->d_status);
   if (s->d_halo_verdict) (void)hipFree(s->d_halo_verdict);
@@ -607,7 +609,7 @@ int check_status(p3d_scene* s) {
   P3D_HIP(hipMemset(s->d_status, 0, sizeof(uint32_t)));
   std::string what;
   if (h & kHoErrTrips) what += " sample hand-out loop reached its trip bound (pixels would miss samples);";
-  if (h & kHoErrLeftoverCap) what += " a hit_stack leftover outgrew its slot;";
+  if (h & kHoErrLeftoverCap) what += " the hit_stack leftovers of this frame do not fit their records (p3d_config.handoff_records = P3D_HANDOFF_DENSE has room for the worst case);";
   if (h & kHoErrNoFixedPoint) what += " hit_stack hand-off did not reach a fixed point;";
   if (h & kHoErrHalo) what += " a row of a stripe / sub-rectangle could not be started on the hit_stack the serial frame hands it (no pixel in front of it certifiably independent of its own incoming stack): render it with more rows in front, as part of the whole frame, or with P3D_STACK_PER_PIXEL;";
   if (h & kHoErrList) what += " a work list of the hit_stack hand-off or a ray queue segment of the per-level launches overflowed;";
@@ -667,6 +669,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   if (cfg->stack_mode > P3D_STACK_PER_PIXEL) return fail(P3D_ERR_INVALID, "bad stack_mode");
   if (cfg->chain_launch > P3D_CHAIN_PER_LEVEL) return fail(P3D_ERR_INVALID, "bad chain_launch");
   if (cfg->debug_view > P3D_DEBUG_DEPTH_MAP) return fail(P3D_ERR_INVALID, "bad debug_view");
+  if (cfg->handoff_records > P3D_HANDOFF_DENSE) return fail(P3D_ERR_INVALID, "bad handoff_records");
   if (cfg->max_depth < 0 || cfg->max_depth > 1024) return fail(P3D_ERR_INVALID, "max_depth out of range");
   if (cfg->antialiasing && (cfg->spp_sqrt == 0 || cfg->spp_sqrt > 1024)) return fail(P3D_ERR_INVALID, "spp_sqrt out of range");
   if (cfg->soft_shadows && !cfg->antialiasing)
@@ -826,9 +829,16 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     // what a pixel can leave behind: the entries its last shading point's feelers left (Q2), one tree path per light
     H.cap = std::max<uint32_t>(1, std::min<uint32_t>(bound, s->dev.n_lights * per));
     if (H.cap > 0xffffu) return fail(P3D_ERR_CAPACITY, "hit_stack leftover bound exceeds 65535 entries (lights x tree depth)");
-    const size_t entry_bytes = (size_t)2 * H.cap * H.n_units * sizeof(uint2);
-    if (entry_bytes > ((size_t)64 << 30)) return fail(P3D_ERR_CAPACITY, "hit_stack hand-off records exceed 64 GiB: render the frame in smaller tiles or use P3D_STACK_PER_PIXEL");
-    if (int rc = s->ho_entries.ensure(entry_bytes)) return rc;
+    // leftover records: a pool with 8 entries per unit on average and an offset table (compact), or the worst case of
+    // every unit (dense: the per-level launches rewrite a unit's record level by level; p3d_config.handoff_records)
+    H.dense = (per_level || cfg->handoff_records == P3D_HANDOFF_DENSE) ? 1u : 0u;
+    uint64_t pool_entries = H.dense ? (uint64_t)2 * H.cap * H.n_units : g_debug_pool_entries ? g_debug_pool_entries : std::max<uint64_t>(1u << 16, (uint64_t)kPoolEntriesPerUnit * H.n_units);
+    if (!H.dense) pool_entries = std::min<uint64_t>(pool_entries, (uint64_t)2 * H.cap * H.n_units);  // never more than dense would take
+    if (pool_entries > 0xffffffffull) return fail(P3D_ERR_CAPACITY, "hit_stack hand-off records exceed 2^32 entries: render the frame in smaller tiles or use P3D_STACK_PER_PIXEL");
+    H.pool_cap = (uint32_t)pool_entries;
+    if (int rc = s->ho_entries.ensure((size_t)pool_entries * sizeof(uint2))) return rc;
+    if (!H.dense)
+      if (int rc = s->ho_where.ensure((size_t)2 * H.n_units * sizeof(uint32_t))) return rc;
     if (int rc = s->ho_meta.ensure((size_t)H.n_units * 4)) return rc;
     if (int rc = s->ho_first.ensure((size_t)H.n_units * sizeof(float4))) return rc;
     if (int rc = s->ho_first_sample.ensure(cfg->antialiasing ? (size_t)H.n_units * 4 : 16)) return rc;
@@ -847,6 +857,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       if (int rc = s->wf_final.ensure((size_t)H.n_units * sizeof(float4))) return rc;
     }
     H.entries = (uint2*)s->ho_entries.p;
+    H.where = (uint32_t*)s->ho_where.p;
     H.meta = (uint32_t*)s->ho_meta.p;
     H.first = (float4*)s->ho_first.p;
     H.first_sample = (uint32_t*)s->ho_first_sample.p;
@@ -871,6 +882,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     for (int i = 0; i < 4; ++i) ho_list[i] = (uint4*)s->ho_lists.p + (size_t)i * H.n_units;
     ho_counters = (uint32_t*)s->ho_counters.p;
     H.counters = ho_counters;
+    H.pool_top = ho_counters + kHoPoolTop;
   }
   if (stats && literal) P3D_HIP(hipEventRecord(s->ev0, st));  // kernel_ms of a LITERAL frame is the whole frame: halo search (when not memoised) and clear included
   uint32_t halo_blocks = 0;
@@ -1053,6 +1065,10 @@ int p3d_debug_set_halo_chain(uint32_t pixels) {
   g_debug_halo_chain = pixels;
   return P3D_OK;
 }
+int p3d_debug_set_leftover_pool(uint32_t entries) {
+  g_debug_pool_entries = entries;
+  return P3D_OK;
+}
 
 int p3d_render_tile(p3d_scene* s, const p3d_config* cfg, const p3d_tile* tile, float* rgb, int32_t* hit_id, uint8_t* rgb8,
                     p3d_stats* stats) {
@@ -1064,8 +1080,14 @@ int p3d_render_tile(p3d_scene* s, const p3d_config* cfg, const p3d_tile* tile, f
   if (hit_id) if (int rc = s->out_hit.ensure(n * sizeof(int32_t))) return rc;
   if (rgb8) if (int rc = s->out_rgb8.ensure(n * 3)) return rc;
   p3d_stats local;
-  const int rc = p3d_render_tile_device(s, cfg, tile, rgb ? (float*)s->out_rgb.p : nullptr, hit_id ? (int32_t*)s->out_hit.p : nullptr,
-                                        rgb8 ? (uint8_t*)s->out_rgb8.p : nullptr, nullptr, stats ? stats : &local);
+  int rc = p3d_render_tile_device(s, cfg, tile, rgb ? (float*)s->out_rgb.p : nullptr, hit_id ? (int32_t*)s->out_hit.p : nullptr,
+                                  rgb8 ? (uint8_t*)s->out_rgb8.p : nullptr, nullptr, stats ? stats : &local);
+  if (rc == P3D_ERR_CAPACITY && cfg->handoff_records == P3D_HANDOFF_COMPACT && std::strstr(p3d_last_error(), "handoff_records")) {
+    p3d_config dense = *cfg;  // the leftover pool was too small for this frame: once more with room for the worst case
+    dense.handoff_records = P3D_HANDOFF_DENSE;
+    rc = p3d_render_tile_device(s, &dense, tile, rgb ? (float*)s->out_rgb.p : nullptr, hit_id ? (int32_t*)s->out_hit.p : nullptr,
+                                rgb8 ? (uint8_t*)s->out_rgb8.p : nullptr, nullptr, stats ? stats : &local);
+  }
   if (rc) return rc;
   if (rgb) P3D_HIP(hipMemcpy(rgb, s->out_rgb.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
   if (hit_id) P3D_HIP(hipMemcpy(hit_id, s->out_hit.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));

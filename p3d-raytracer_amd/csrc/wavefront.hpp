@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
       if (!chain_ended || LIT == 1) {
         uint32_t n = (uint32_t)st.sp;
         if (n > H.cap) { atomicOr(P.status, kHoErrLeftoverCap); n = H.cap; }
-        for (uint32_t e = 0; e < n; ++e) H.entries[(size_t)e * H.n_units + unit] = stack_read<SPILL>(st, (int)e);
+        for (uint32_t e = 0; e < n; ++e) H.entries[(size_t)unit * H.cap + e] = stack_read<SPILL>(st, (int)e);  // (dense records: slot 0 of the unit)
         if (level == 0) {
           uint32_t meta = n;
           if (LIT == 1 && unit_touched) {

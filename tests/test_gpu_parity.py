@@ -461,6 +461,36 @@ def test_row_starts_are_certified_or_the_call_fails(scene, legacy, res):
     assert dev.status() == 0
 
 
+def test_leftover_pool_that_runs_full_fails_or_falls_back_to_dense_records():
+    """P3D_STACK_LITERAL keeps what every pixel leaves on the stack.  Compact records (default): a pool of 8 entries per
+    pixel on average; dense records: the worst case of every pixel.  A frame that outgrows the pool must not come back
+    wrong: the device-buffer call fails (p3d_scene_status), the host-buffer call renders again with dense records by
+    itself - and either way the frame is the one the dense records give (forced here by shrinking the pool)."""
+    import torch
+    dev, sc = _pair(scene_path("balls_low.p3f"), res=(192, 192), grid=False)
+    cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4)
+    dense = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4, handoff_records=p3d.HANDOFF_DENSE)
+    want, want_hit, _ = dev.render(dense)
+    got, got_hit, _ = dev.render(cfg)
+    assert (got.view(np.uint32) == want.view(np.uint32)).all() and (got_hit == want_hit).all()
+    o_rgb, o_hit, _ = sc.render(oracle_cfg_like(cfg))
+    assert_bit_identical((want, want_hit), (o_rgb, o_hit), "dense records")
+    n = 192 * 192
+    buf = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
+    L = p3d.lib()
+    try:
+        L.p3d_debug_set_leftover_pool(2000)  # this frame leaves about 0.3 entries per pixel: 36 864 pixels need far more than that
+        dev.render_device(cfg, dev.full_tile(), d_rgb=buf.data_ptr(), d_hit=buf.data_ptr() + n * 12)
+        code = dev.status()
+        msg = p3d.lib().p3d_last_error().decode()
+        again, again_hit, _ = dev.render(cfg)  # host-buffer call: falls back to dense records when the pool is too small
+    finally:
+        L.p3d_debug_set_leftover_pool(0)
+    assert code == -4 and "handoff_records" in msg, (code, msg)
+    assert (again.view(np.uint32) == want.view(np.uint32)).all() and (again_hit == want_hit).all()
+    assert dev.status() == 0
+
+
 def test_hand_off_that_runs_out_of_rounds_is_an_error_also_without_stats():
     """The hit_stack hand-off iterates its work lists to a fixed point; a list that is still not empty after the round
     bound means the frame is not the serial one.  That must fail the call - also on the asynchronous path (device
