@@ -596,8 +596,6 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
       }
 
       bool unit_touched = false;
-      float4 unit_first = make_float4(0.f, 0.f, 0.f, 0.f);
-      uint32_t unit_first_sample = 0;
       uint32_t unit_ch0[kCh0Counters] = {0, 0, 0, 0, 0};
       if (STATS && LIT != 0) ct.clear();  // LITERAL: counters per unit (store_unit_counters), not per lane
       if (LIT == 2 && active) {  // seed with the predecessor's leftover; re-trace the first closest hit if asked to
@@ -729,8 +727,6 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
             if (n > H.cap) { atomicOr(P.status, kHoErrLeftoverCap); n = H.cap; }
             leave_n = n;
             meta = n | kMetaTouched;
-            H.first[unit] = unit_first;
-            if (AA) H.first_sample[unit] = unit_first_sample;
             atomicOr(&H.touched[unit >> 5], 1u << (unit & 31u));
           }
           H.meta[unit] = meta;
@@ -750,7 +746,6 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
             const uint2 a = H.entries[old_at + e], b = stack_read<SPILL>(st, (int)e);
             same = a.x == b.x && a.y == b.y;
           }
-          H.first[unit] = unit_first;
           if (!same) {
             leave_n = n;
             leave_slot = cur ^ 1u;

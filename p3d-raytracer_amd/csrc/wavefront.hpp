@@ -133,8 +133,6 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
       Rng rng;
       rng.state = 0; rng.inc = 1;
       bool unit_touched = false;
-      float4 unit_first = make_float4(0.f, 0.f, 0.f, 0.f);
-      uint32_t unit_first_sample = 0;
       uint32_t unit_ch0[kCh0Counters] = {0, 0, 0, 0, 0};
       F3 chain_result = f3(0, 0, 0);
       constexpr bool COLD = false;
@@ -145,7 +143,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
 #define P3D_FIRST_HIT(obj) first_hit = (obj)
 #include "whitted_level.inc"
 #undef P3D_FIRST_HIT
-      (void)n_deferred; (void)unit_first_sample;
+      (void)n_deferred;
       if (STATS && LIT == 1) {  // counters per unit, accumulated level by level (handoff.hpp: ucount)
         if (up.halo) ct.clear();
         if (level == 0) {
@@ -183,7 +181,6 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
           uint32_t meta = n;
           if (LIT == 1 && unit_touched) {
             meta |= kMetaTouched;
-            H.first[unit] = unit_first;
             atomicOr(&H.touched[unit >> 5], 1u << (unit & 31u));
           }
           H.meta[unit] = meta;
