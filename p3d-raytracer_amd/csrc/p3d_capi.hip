@@ -69,7 +69,7 @@ struct Scratch {
 // given key runs in frame order and records what every tile cost, the launches after it take
 // the tiles most-expensive-class first.
 struct SchedEntry {
-  uint32_t accel = 0, aa = 0, spp = 0, pt = 0, max_split = 0;
+  uint32_t accel = 0, aa = 0, spp = 0, pt = 0, max_split = 0, tiles_x = 0, tiles_y = 0;  // (tiles: 8x8 or 4x4 pixels, by kernel variant)
   int32_t max_depth = 0, x0 = 0, y0 = 0, w = 0, h = 0, stripe_h = 0, stripe_stride = 0;
   Scratch cost, sched;
   hipEvent_t ready = nullptr;
@@ -77,7 +77,7 @@ struct SchedEntry {
   uint64_t last_use = 0;
   bool built = false;  // the recording launch and sched_build_kernel were enqueued: `sched` may be used
   bool same_key(const SchedEntry& o) const {
-    return accel == o.accel && aa == o.aa && spp == o.spp && pt == o.pt && max_split == o.max_split && max_depth == o.max_depth && x0 == o.x0 && y0 == o.y0 &&
+    return accel == o.accel && aa == o.aa && spp == o.spp && pt == o.pt && max_split == o.max_split && tiles_x == o.tiles_x && tiles_y == o.tiles_y && max_depth == o.max_depth && x0 == o.x0 && y0 == o.y0 &&
            w == o.w && h == o.h && stripe_h == o.stripe_h && stripe_stride == o.stripe_stride;
   }
 };
@@ -543,7 +543,7 @@ hipError_t launch_literal(int lit, bool aa, bool lds_scene, bool stats, const Re
 int schedule_lookup(p3d_scene* s, const p3d_config* cfg, bool pt, uint32_t max_split, RenderParams& P, hipStream_t st, SchedEntry** fresh) {
   *fresh = nullptr;
   SchedEntry key;
-  key.accel = cfg->accel; key.aa = cfg->antialiasing ? 1 : 0; key.spp = cfg->antialiasing ? cfg->spp_sqrt : 1; key.pt = pt ? 1 : 0; key.max_split = max_split;
+  key.accel = cfg->accel; key.aa = cfg->antialiasing ? 1 : 0; key.spp = cfg->antialiasing ? cfg->spp_sqrt : 1; key.pt = pt ? 1 : 0; key.max_split = max_split; key.tiles_x = P.tiles_x; key.tiles_y = P.tiles_y;
   key.max_depth = P.max_depth; key.x0 = P.x0; key.y0 = P.y0; key.w = P.w; key.h = P.h;
   key.stripe_h = P.stripe_h; key.stripe_stride = P.stripe_stride;
   for (SchedEntry& c : s->sched)
@@ -568,7 +568,7 @@ int schedule_lookup(p3d_scene* s, const p3d_config* cfg, bool pt, uint32_t max_s
   if (int rc = e->cost.ensure((size_t)n * sizeof(uint32_t))) return rc;
   if (int rc = e->sched.ensure(((size_t)n + 3 * (size_t)kMaxSplitTiles + 1) * sizeof(uint32_t))) return rc;  // [0] = entries; a split tile has four
   if (!e->ready) P3D_HIP(hipEventCreateWithFlags(&e->ready, hipEventDisableTiming));
-  e->accel = key.accel; e->aa = key.aa; e->spp = key.spp; e->pt = key.pt; e->max_split = key.max_split; e->max_depth = key.max_depth; e->x0 = key.x0; e->y0 = key.y0;
+  e->accel = key.accel; e->aa = key.aa; e->spp = key.spp; e->pt = key.pt; e->max_split = key.max_split; e->tiles_x = key.tiles_x; e->tiles_y = key.tiles_y; e->max_depth = key.max_depth; e->x0 = key.x0; e->y0 = key.y0;
   e->w = key.w; e->h = key.h; e->stripe_h = key.stripe_h; e->stripe_stride = key.stripe_stride;
   P.tile_cost = (uint32_t*)e->cost.p;
   *fresh = e;

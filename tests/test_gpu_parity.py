@@ -491,6 +491,26 @@ def test_leftover_pool_that_runs_full_fails_or_falls_back_to_dense_records():
     assert dev.status() == 0
 
 
+def test_tile_schedules_of_different_kernel_variants_do_not_mix(tri5k_path):
+    """The recorded tile schedule belongs to a tile GRID: the literal anti-aliased launch works on 8x8-pixel tiles, the
+    per-pixel one over a scene traversed from L2 on 4x4 tiles with four lanes per pixel.  Rendering one after the other
+    on one scene (found by the round-3 fuzz campaign: the second launch took the first one's schedule and rendered a
+    quarter of its tiles) must give each its own frame, first launch (recording) and second (scheduled)."""
+    dev, sc = _pair(tri5k_path, res=(192, 160), grid=False)
+    kw = dict(antialiasing=1, spp_sqrt=2, soft_shadows=1, seed=9)
+    lit = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=3, collect_stats=1, **kw)
+    pp = per_pixel(lit)
+    want = {}
+    for name, cfg in (("literal", lit), ("per-pixel", pp)):
+        want[name] = sc.render(oracle_cfg_like(cfg))
+    for round_ in range(2):
+        for name, cfg in (("literal", lit), ("per-pixel", pp)):
+            rgb, hit, st = dev.render(cfg)
+            o_rgb, o_hit, o_st = want[name]
+            assert st.rays_primary == o_st.rays_primary == 192 * 160 * 4, (name, round_)
+            assert (hit == o_hit).all() and np.abs(rgb - o_rgb).max() <= 5e-6, (name, round_)
+
+
 def test_hand_off_that_runs_out_of_rounds_is_an_error_also_without_stats():
     """The hit_stack hand-off iterates its work lists to a fixed point; a list that is still not empty after the round
     bound means the frame is not the serial one.  That must fail the call - also on the asynchronous path (device
