@@ -131,8 +131,13 @@ struct RayS {
   bool settled;
   bool odd_inv;  // some 1/d component is +-inf or NaN: the slab test can then produce NaNs (0 * inf)
 };
+// "odd": some 1/d component is +-inf or NaN (the slab test can then produce NaNs, 0 * inf), or smaller than 0.75 in
+// magnitude (|d| > 1.33: never a ray of the renderer, whose directions are normalised; possible through p3d_trace_*).  For a
+// wave without an odd lane the slab products keep the sign of their factors exactly (|x * inv| >= 0.75 |x| cannot round
+// to zero for x != 0) and no NaN can arise: the fast paths of aabb_intercepts and bvh_closest rely on both.
 __device__ __forceinline__ bool inv_is_odd(F3 inv) {
-  return !(fabsf(inv.x) < INFINITY) || !(fabsf(inv.y) < INFINITY) || !(fabsf(inv.z) < INFINITY);
+  const float ax = fabsf(inv.x), ay = fabsf(inv.y), az = fabsf(inv.z);
+  return !(ax < INFINITY && ax >= 0.75f) || !(ay < INFINITY && ay >= 0.75f) || !(az < INFINITY && az >= 0.75f);
 }
 __device__ __forceinline__ void ray_set(RayS& r, F3 o, F3 d) {
   r.o = o;
@@ -214,6 +219,7 @@ struct DevScene {
   const float4* lights;
   const uint32_t* emitters;  // object ids of emissive spheres, object order (main.cpp:407-415)
   uint32_t n_nodes, n_slots, n_objs, n_mats, n_lights, n_emitters;
+  uint32_t odd_boxes;  // some node box is not finite or has min > max: the slab fast paths are off for this scene
   DevCamera cam;
   F3 bg;
   DevGrid grid;
@@ -346,7 +352,9 @@ __device__ __forceinline__ uint32_t geom_object(const Geom& g) { return __float_
 // WAVE-UNIFORM promise that no lane's 1/d has an inf/NaN component: then no NaN can arise,
 // the chains equal plain max/min and one v_max3_f32 / v_min3_f32 each replaces 12 compares
 // and selects (the sign of a zero result is never observable: only orderings of t matter).
-__device__ __forceinline__ bool aabb_intercepts(F3 mn, F3 mx, const RayS& r, float& t, bool all_finite) {
+// t0 / t1 (optional): the slab interval itself, for bvh_closest's fast isInside.
+__device__ __forceinline__ bool aabb_intercepts(F3 mn, F3 mx, const RayS& r, float& t, bool all_finite, float* t0_out = nullptr,
+                                                float* t1_out = nullptr) {
   const float a = r.inv.x, b = r.inv.y, c = r.inv.z;
   const float tx_min = ((a >= 0 ? mn.x : mx.x) - r.o.x) * a, tx_max = ((a >= 0 ? mx.x : mn.x) - r.o.x) * a;
   const float ty_min = ((b >= 0 ? mn.y : mx.y) - r.o.y) * b, ty_max = ((b >= 0 ? mx.y : mn.y) - r.o.y) * b;
@@ -359,6 +367,8 @@ __device__ __forceinline__ bool aabb_intercepts(F3 mn, F3 mx, const RayS& r, flo
     t1 = min3_ref(tx_max, ty_max, tz_max);
   }
   t = (t0 < 0) ? t1 : t0;
+  if (t0_out) *t0_out = t0;
+  if (t1_out) *t1_out = t1;
   return (t0 < t1) && gt_1em4(t1);
 }
 __device__ __forceinline__ bool is_inside(F3 mn, F3 mx, F3 p) {  // boundingBox.cpp:39-42 (strict)
@@ -493,7 +503,7 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
   int hit = -1;
   const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
-  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, !__any(ray.odd_inv))) return -1;  // stale entries stay (Q2)
+  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, (!sc.odd_boxes && !__any(ray.odd_inv)))) return -1;  // stale entries stay (Q2)
   if (root_passed) *root_passed = true;
   // The traversal state is ONE word: the descriptor of the node the lane stands on, or kDescDone (leaf bit set, so
   // that a finished lane also falls out of the descend loop): fewer lane masks for the compiler to carry round the loops.
@@ -505,11 +515,24 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
       float l_t, r_t;
       ct.add(kNodeTests, 2);
-      const bool fin = !__any(ray.odd_inv);  // wave-uniform: may the slab tests use max3/min3?
-      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin);
-      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin);
-      if (is_inside(xyz(l.lo), xyz(l.hi), ray.o)) l_t = 0;  // bvh.cpp:216-217
-      if (is_inside(xyz(r.lo), xyz(r.hi), ray.o)) r_t = 0;
+      const bool fin = (!sc.odd_boxes && !__any(ray.odd_inv));  // wave-uniform: may the slab tests use max3/min3?
+      float l_t0, l_t1, r_t0, r_t1;
+      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin, &l_t0, &l_t1);
+      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin, &r_t0, &r_t1);
+      // bvh.cpp:216-217: an origin strictly inside a child's box makes that child's distance 0.  Without an odd lane in
+      // the wave every slab product has exactly the sign of (plane - origin) * (1/d) and none is a NaN, so the origin lies
+      // strictly between the two planes of an axis iff that axis' near product is < 0 and its far product > 0, and inside
+      // the box iff t0 = max(near products) < 0 and t1 = min(far products) > 0: two compares instead of the twelve of
+      // AABB::isInside (boundingBox.cpp:39-42), same truth value (boxes with min <= max: what a BVH build produces; a
+      // descriptor with an inverted box makes the scene take the slow path, p3d_scene_create).  Otherwise the test as the
+      // reference writes it.
+      if (fin) {
+        if (l_t0 < 0 && l_t1 > 0) l_t = 0;
+        if (r_t0 < 0 && r_t1 > 0) r_t = 0;
+      } else {
+        if (is_inside(xyz(l.lo), xyz(l.hi), ray.o)) l_t = 0;
+        if (is_inside(xyz(r.lo), xyz(r.hi), ray.o)) r_t = 0;
+      }
       const uint32_t ld = __float_as_uint(l.lo.w), rd = __float_as_uint(r.lo.w);
       if (l_hit && r_hit) {
         if (l_t < r_t) { desc = ld; push<SPILL>(st, rd, r_t, ct); }
@@ -547,7 +570,7 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
   float tmp;
   const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
-  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, !__any(ray.odd_inv))) return false;
+  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, (!sc.odd_boxes && !__any(ray.odd_inv)))) return false;
   // state word as in bvh_closest, with a second end state: kDescHit = a primitive was hit (no flag to carry round the loops)
   uint32_t desc = __float_as_uint(root.lo.w);
   // bvh.cpp:329-338: pop all, continue from the first-pushed entry; nothing left = done
@@ -565,7 +588,7 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
       float l_t, r_t;
       ct.add(kNodeTests, 2);
-      const bool fin = !__any(ray.odd_inv);
+      const bool fin = (!sc.odd_boxes && !__any(ray.odd_inv));
       const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin);
       const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin);
       const uint32_t ld = __float_as_uint(l.lo.w), rd = __float_as_uint(r.lo.w);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -265,6 +266,7 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
   blob.push_back(make_float4(0, 0, 0, 0));
   s->off_nodes = (uint32_t)blob.size();
   uint32_t n_nodes_out = 0;
+  bool odd_boxes = false;
   if (d->n_bvh_nodes) {
     const p3d_bvh_node* N = d->bvh_nodes;
     auto inner = [&](uint32_t i) { return !(N[i].count_leaf & P3D_BVH_LEAF); };
@@ -303,7 +305,8 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
       float descf;
       std::memcpy(&descf, &desc, 4);
       blob[s->off_nodes + 2 * (size_t)at] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], descf);
-      blob[s->off_nodes + 2 * (size_t)at + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], 0.f);
+      blob[s->off_nodes + 2 * (size_t)at + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], 0.f);      for (int k = 0; k < 3; ++k)  // the slab fast paths assume finite boxes with min <= max (device_core.hpp)
+        if (!(std::fabs(n.bmin[k]) < INFINITY) || !(std::fabs(n.bmax[k]) < INFINITY) || !(n.bmin[k] <= n.bmax[k])) odd_boxes = true;
     };
     put(0, 0);
     for (uint32_t i = 0; i < d->n_bvh_nodes; ++i)
@@ -366,6 +369,7 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
   v.lights = s->d_blob + s->off_lights;
   v.emitters = s->d_emitters;
   v.n_nodes = n_nodes_out;
+  v.odd_boxes = odd_boxes ? 1u : 0u;
   v.n_slots = d->n_bvh_prim_index;
   v.n_objs = d->n_prims;
   v.n_mats = d->n_materials;
@@ -380,6 +384,10 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
   if (device_bvh && d->n_prims) {
     if (d->n_prims > 0x07ffffffu) return fail(P3D_ERR_CAPACITY, "p3d_scene_create_device_bvh: too many objects");
     std::vector<float4> boxes((size_t)2 * d->n_prims);
+    for (uint32_t i = 0; i < d->n_prims; ++i)
+      for (int k = 0; k < 3; ++k)
+        if (!(std::fabs(d->prims[i].bmin[k]) < INFINITY) || !(std::fabs(d->prims[i].bmax[k]) < INFINITY) || !(d->prims[i].bmin[k] <= d->prims[i].bmax[k]))
+          v.odd_boxes = 1u;  // (the built tree's boxes are unions of these)
     for (uint32_t i = 0; i < d->n_prims; ++i) {
       boxes[2 * i] = make_float4(d->prims[i].bmin[0], d->prims[i].bmin[1], d->prims[i].bmin[2], 0.f);
       boxes[2 * i + 1] = make_float4(d->prims[i].bmax[0], d->prims[i].bmax[1], d->prims[i].bmax[2], 0.f);
