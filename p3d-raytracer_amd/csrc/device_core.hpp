@@ -452,6 +452,10 @@ __device__ __forceinline__ F3 get_normal(const Geom& g, const float4* normals, F
 // Node descriptor, packed at upload into one word (carried in lo.w and on the stack):
 //   bit 31 = leaf, bits 30..28 = object count of a leaf (<= 7), bits 27..0 = left child
 //   (inner) or first leaf slot (leaf).
+#ifndef P3D_VOTE_NUM  // a step down is taken when lanes_on_inner * DEN >= lanes_on_leaf * NUM (bvh_closest, VOTE)
+#define P3D_VOTE_NUM 1
+#define P3D_VOTE_DEN 1
+#endif
 constexpr uint32_t kDescLeaf = 0x80000000u;
 constexpr uint32_t kDescDone = 0xffffffffu;  // traversal state "no node left"; never a descriptor (it would be a leaf of 7 objects at slot 2^28 - 1)
 constexpr uint32_t kDescHit = 0xfffffffeu;   // any-hit traversal state "a primitive was hit" (nor this: slot 2^28 - 2); both have the leaf bit
@@ -496,7 +500,55 @@ __device__ __forceinline__ uint32_t pop_closer(Stack& st, float tmin) {
 // *root_passed (optional): the ray got past the root test of bvh.cpp:203-205, i.e. the query touched hit_stack
 // and left it empty; a ray that fails it returns with the stack exactly as it found it.
 // *final_ray (optional): the private copy as the traversal leaves it (its direction re-normalised by the sphere tests it ran).
-template <bool SPILL, class CT>
+// The two kinds of step of the closest-hit traversal, as text: both loop skeletons below (nested loops / vote) get exactly
+// this code inline (as lambdas they cost the global-memory kernels 70 bytes of scratch per lane and 15 % of their speed).
+// One step down: bvh.cpp:208-239 (ties go right, Q10).  A leaf: bvh.cpp:241-252, then the pop loop.
+// (in the step down) bvh.cpp:216-217: an origin strictly inside a child's box makes that child's distance 0.  Without an odd
+// lane in the wave every slab product has exactly the sign of (plane - origin) * (1/d) and none is a NaN, so the origin lies
+// strictly between the two planes of an axis iff that axis' near product is < 0 and its far product > 0, and inside the box
+// iff t0 = max(near products) < 0 and t1 = min(far products) > 0: two compares instead of the twelve of AABB::isInside
+// (boundingBox.cpp:39-42), same truth value (boxes with min <= max: what a BVH build produces; a descriptor with an inverted
+// box makes the scene take the slow path, p3d_scene_create).  Otherwise the test as the reference writes it.
+#define P3D_CLOSEST_DESCEND_STEP \
+  {\
+      const uint32_t index = desc_index(desc);\
+      const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);\
+      float l_t, r_t;\
+      ct.add(kNodeTests, 2);\
+      const bool fin = (!sc.odd_boxes && !__any(ray.odd_inv));\
+      float l_t0, l_t1, r_t0, r_t1;\
+      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin, &l_t0, &l_t1);\
+      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin, &r_t0, &r_t1);\
+      if (fin) {\
+        if (l_t0 < 0 && l_t1 > 0) l_t = 0;\
+        if (r_t0 < 0 && r_t1 > 0) r_t = 0;\
+      } else {\
+        if (is_inside(xyz(l.lo), xyz(l.hi), ray.o)) l_t = 0;\
+        if (is_inside(xyz(r.lo), xyz(r.hi), ray.o)) r_t = 0;\
+      }\
+      const uint32_t ld = __float_as_uint(l.lo.w), rd = __float_as_uint(r.lo.w);\
+      if (l_hit && r_hit) {\
+        if (l_t < r_t) { desc = ld; push<SPILL>(st, rd, r_t, ct); }\
+        else           { desc = rd; push<SPILL>(st, ld, l_t, ct); }\
+      } else if (l_hit) { desc = ld; }\
+      else if (r_hit)   { desc = rd; }\
+      else desc = pop_closer<SPILL>(st, tmin);\
+  }
+#define P3D_CLOSEST_LEAF_STEP \
+  {\
+      const uint32_t index = desc_index(desc), n = desc_count(desc);\
+      for (uint32_t s = index; s < index + n; ++s) {\
+        const Geom g = load_geom(sc.bgeom, s);\
+        float curr_t;\
+        if (intercepts(g, ray, curr_t, ct) && curr_t < tmin) {\
+          tmin = curr_t;\
+          hit = (int)s;\
+          hit_geom = g;\
+        }\
+      }\
+      desc = pop_closer<SPILL>(st, tmin);\
+  }
+template <bool SPILL, class CT, bool VOTE = SPILL>
 __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_point, Geom& hit_geom, CT& ct,
                            bool* root_passed = nullptr, float* t_out = nullptr, RayS* final_ray = nullptr) {
   float tmp, tmin = FLT_MAX;
@@ -508,52 +560,25 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
   // The traversal state is ONE word: the descriptor of the node the lane stands on, or kDescDone (leaf bit set, so
   // that a finished lane also falls out of the descend loop): fewer lane masks for the compiler to carry round the loops.
   uint32_t desc = __float_as_uint(root.lo.w);
-  while (desc != kDescDone) {
-    // ---- descend: bvh.cpp:208-239 ----
-    while (!(desc & kDescLeaf)) {
-      const uint32_t index = desc_index(desc);
-      const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
-      float l_t, r_t;
-      ct.add(kNodeTests, 2);
-      const bool fin = (!sc.odd_boxes && !__any(ray.odd_inv));  // wave-uniform: may the slab tests use max3/min3?
-      float l_t0, l_t1, r_t0, r_t1;
-      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin, &l_t0, &l_t1);
-      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin, &r_t0, &r_t1);
-      // bvh.cpp:216-217: an origin strictly inside a child's box makes that child's distance 0.  Without an odd lane in
-      // the wave every slab product has exactly the sign of (plane - origin) * (1/d) and none is a NaN, so the origin lies
-      // strictly between the two planes of an axis iff that axis' near product is < 0 and its far product > 0, and inside
-      // the box iff t0 = max(near products) < 0 and t1 = min(far products) > 0: two compares instead of the twelve of
-      // AABB::isInside (boundingBox.cpp:39-42), same truth value (boxes with min <= max: what a BVH build produces; a
-      // descriptor with an inverted box makes the scene take the slow path, p3d_scene_create).  Otherwise the test as the
-      // reference writes it.
-      if (fin) {
-        if (l_t0 < 0 && l_t1 > 0) l_t = 0;
-        if (r_t0 < 0 && r_t1 > 0) r_t = 0;
-      } else {
-        if (is_inside(xyz(l.lo), xyz(l.hi), ray.o)) l_t = 0;
-        if (is_inside(xyz(r.lo), xyz(r.hi), ray.o)) r_t = 0;
-      }
-      const uint32_t ld = __float_as_uint(l.lo.w), rd = __float_as_uint(r.lo.w);
-      if (l_hit && r_hit) {
-        if (l_t < r_t) { desc = ld; push<SPILL>(st, rd, r_t, ct); }
-        else           { desc = rd; push<SPILL>(st, ld, l_t, ct); }  // ties go right (Q10)
-      } else if (l_hit) { desc = ld; }
-      else if (r_hit)   { desc = rd; }
-      else desc = pop_closer<SPILL>(st, tmin);
+  if (VOTE) {
+    // Every lane walks its own sequence of steps down and leaves; the wave can only take one kind of step at a time and
+    // the lanes that need the other kind sit it out.  "Leaves only when nobody is on an inner node" (the nested loops
+    // below) lets a few long descents hold up everyone who already stands on a leaf; here the kind that has the
+    // majority goes next (a leaf step costs about as much as a step down).  The order of a LANE's visits, tests, pushes
+    // and pops is untouched, so are the bits.  100k triangles 2048x2048: 16.9 -> 15.0 ms (literal 18.1 -> 16.2); not for
+    // LDS-staged scenes, whose phases are a handful of steps long (the ballots cost more than the waiting: cfg2 -7 %).
+    while (true) {
+      const bool on_inner = !(desc & kDescLeaf), on_leaf = !on_inner && desc != kDescDone;
+      const unsigned long long m_inner = __ballot(on_inner), m_leaf = __ballot(on_leaf);
+      if ((m_inner | m_leaf) == 0) break;
+      const bool descend = m_leaf == 0 || __popcll(m_inner) * P3D_VOTE_DEN >= __popcll(m_leaf) * P3D_VOTE_NUM;  // wave-uniform
+      if (descend && on_inner) P3D_CLOSEST_DESCEND_STEP
+      if (!descend && on_leaf) P3D_CLOSEST_LEAF_STEP
     }
-    // ---- leaf: bvh.cpp:241-252, then the pop loop ----
-    if (desc != kDescDone) {
-      const uint32_t index = desc_index(desc), n = desc_count(desc);
-      for (uint32_t s = index; s < index + n; ++s) {
-        const Geom g = load_geom(sc.bgeom, s);
-        float curr_t;
-        if (intercepts(g, ray, curr_t, ct) && curr_t < tmin) {
-          tmin = curr_t;
-          hit = (int)s;
-          hit_geom = g;
-        }
-      }
-      desc = pop_closer<SPILL>(st, tmin);
+  } else {
+    while (desc != kDescDone) {
+      while (!(desc & kDescLeaf)) P3D_CLOSEST_DESCEND_STEP
+      if (desc != kDescDone) P3D_CLOSEST_LEAF_STEP
     }
   }
   if (hit >= 0) hit_point = ray.d * tmin + ray.o;
@@ -565,7 +590,40 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
 // Any hit.  Q1: after a dead end the reference pops EVERYTHING and resumes at the
 // bottom-most entry; Q2: an early `return true` leaves its entries on the stack for the
 // next query of the same pixel.
-template <bool SPILL, class CT>
+// ... and of the any-hit traversal (bvh.cpp:278-340): a step down; a leaf (a hit ends the query, its entries stay behind: Q2).
+#define P3D_ANY_DESCEND_STEP \
+  {\
+      const uint32_t index = desc_index(desc);\
+      const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);\
+      float l_t, r_t;\
+      ct.add(kNodeTests, 2);\
+      const bool fin = (!sc.odd_boxes && !__any(ray.odd_inv));\
+      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin);\
+      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin);\
+      const uint32_t ld = __float_as_uint(l.lo.w), rd = __float_as_uint(r.lo.w);\
+      if (l_hit && r_hit) {\
+        if (l_t < r_t) { desc = ld; push<SPILL>(st, rd, r_t, ct); }\
+        else           { desc = rd; push<SPILL>(st, ld, l_t, ct); }\
+      } else if (l_hit) { desc = ld; }\
+      else if (r_hit)   { desc = rd; }\
+      else restart_from_bottom();\
+  }
+#define P3D_ANY_LEAF_STEP \
+  {\
+      uint32_t s = desc_index(desc);\
+      const uint32_t end = s + desc_count(desc);\
+      bool occluded = false, more = s < end;\
+      while (more) {\
+        const Geom g = load_geom(sc.bgeom, s);\
+        float curr_t;\
+        occluded = intercepts(g, ray, curr_t, ct);\
+        ++s;\
+        more = !occluded && s < end;\
+      }\
+      if (occluded) desc = kDescHit;\
+      else restart_from_bottom();\
+  }
+template <bool SPILL, class CT, bool VOTE = SPILL>
 __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
   float tmp;
   const NodeRec root = load_node(sc.nodes, 0);
@@ -582,36 +640,19 @@ __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
       desc = kDescDone;
     }
   };
-  while (desc < kDescHit) {
-    while (!(desc & kDescLeaf)) {
-      const uint32_t index = desc_index(desc);
-      const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);
-      float l_t, r_t;
-      ct.add(kNodeTests, 2);
-      const bool fin = (!sc.odd_boxes && !__any(ray.odd_inv));
-      const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin);
-      const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin);
-      const uint32_t ld = __float_as_uint(l.lo.w), rd = __float_as_uint(r.lo.w);
-      if (l_hit && r_hit) {
-        if (l_t < r_t) { desc = ld; push<SPILL>(st, rd, r_t, ct); }
-        else           { desc = rd; push<SPILL>(st, ld, l_t, ct); }
-      } else if (l_hit) { desc = ld; }
-      else if (r_hit)   { desc = rd; }
-      else restart_from_bottom();
+  if (VOTE) {  // (see bvh_closest)
+    while (true) {
+      const bool on_inner = !(desc & kDescLeaf), on_leaf = !on_inner && desc < kDescHit;
+      const unsigned long long m_inner = __ballot(on_inner), m_leaf = __ballot(on_leaf);
+      if ((m_inner | m_leaf) == 0) break;
+      const bool descend = m_leaf == 0 || __popcll(m_inner) * P3D_VOTE_DEN >= __popcll(m_leaf) * P3D_VOTE_NUM;
+      if (descend && on_inner) P3D_ANY_DESCEND_STEP
+      if (!descend && on_leaf) P3D_ANY_LEAF_STEP
     }
-    if (desc < kDescHit) {
-      uint32_t s = desc_index(desc);
-      const uint32_t end = s + desc_count(desc);
-      bool occluded = false, more = s < end;
-      while (more) {  // one loop condition, no exit from the middle (see pop_closer)
-        const Geom g = load_geom(sc.bgeom, s);
-        float curr_t;
-        occluded = intercepts(g, ray, curr_t, ct);  // a hit ends the query; its entries stay behind (Q2)
-        ++s;
-        more = !occluded && s < end;
-      }
-      if (occluded) desc = kDescHit;
-      else restart_from_bottom();
+  } else {
+    while (desc < kDescHit) {
+      while (!(desc & kDescLeaf)) P3D_ANY_DESCEND_STEP
+      if (desc < kDescHit) P3D_ANY_LEAF_STEP
     }
   }
   return desc == kDescHit;
@@ -763,11 +804,13 @@ __device__ bool grid_any(const DevScene& sc, RayS& ray, CT& ct) {
 // (main.cpp:164): o + d*min_t with the caller's (mutated) ray for accel None, the
 // traversal's hit point otherwise.
 // ---------------------------------------------------------------------------
-template <int ACCEL, bool SPILL, class CT>
+// VOTE: the BVH loops take the kind of step the majority of the wave's lanes needs (bvh_closest); for scenes traversed from
+// global memory, not for LDS-staged ones.
+template <int ACCEL, bool SPILL, bool VOTE, class CT>
 __device__ __forceinline__ int closest_hit(const DevScene& sc, Stack& st, RayS& ray, F3& P, Geom& g, CT& ct,
                                            bool* root_passed = nullptr, float* t_out = nullptr) {
   if (ACCEL == P3D_ACCEL_BVH) {
-    const int slot = bvh_closest<SPILL>(sc, st, ray, P, g, ct, root_passed, t_out);
+    const int slot = bvh_closest<SPILL, CT, VOTE>(sc, st, ray, P, g, ct, root_passed, t_out);
     return slot < 0 ? -1 : (int)geom_object(g);
   } else if (ACCEL == P3D_ACCEL_GRID) {
     return grid_closest(sc, ray, P, g, ct, t_out);
@@ -780,9 +823,9 @@ __device__ __forceinline__ int closest_hit(const DevScene& sc, Stack& st, RayS& 
   }
 }
 // Shadow feeler (main.cpp:196-217).  Q6: with the grid, brute force runs as well.
-template <int ACCEL, bool SPILL, class CT>
+template <int ACCEL, bool SPILL, bool VOTE, class CT>
 __device__ __forceinline__ bool any_hit(const DevScene& sc, Stack& st, RayS& feeler, CT& ct) {
-  if (ACCEL == P3D_ACCEL_BVH) return bvh_any<SPILL>(sc, st, feeler, ct);
+  if (ACCEL == P3D_ACCEL_BVH) return bvh_any<SPILL, CT, VOTE>(sc, st, feeler, ct);
   bool occluded = false;
   if (ACCEL == P3D_ACCEL_GRID) occluded = grid_any(sc, feeler, ct);
   const bool b = brute_any(sc, feeler, ct);

@@ -464,7 +464,7 @@ __device__ __forceinline__ bool same_first(float4 a, float4 b) {
          __float_as_uint(a.z) == __float_as_uint(b.z) && __float_as_uint(a.w) == __float_as_uint(b.w);
 }
 // The first closest hit of a unit's first touching sample, traced on whatever the stack holds (bvh.cpp:198-276).
-template <bool SPILL, class CT>
+template <bool SPILL, bool VOTE, class CT>
 __device__ __forceinline__ float4 first_closest_hit(const RenderParams& P, const DevScene& sc, Stack& st, int x, int y, uint32_t sample, CT& ct) {
   Rng rng;
   rng.state = 0; rng.inc = 1;
@@ -476,7 +476,7 @@ __device__ __forceinline__ float4 first_closest_hit(const RenderParams& P, const
   RayS ray;
   ray_set(ray, o, d);
   Geom g;
-  const int obj = closest_hit<P3D_ACCEL_BVH, SPILL>(sc, st, ray, Pn, g, ct);
+  const int obj = closest_hit<P3D_ACCEL_BVH, SPILL, VOTE>(sc, st, ray, Pn, g, ct);
   return obj < 0 ? make_float4(0.f, 0.f, 0.f, __int_as_float(-1)) : make_float4(Pn.x, Pn.y, Pn.z, __int_as_float(obj));
 }
 
@@ -527,6 +527,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
   const uint32_t gid = blockIdx.x * kBlock + lane;
   // cold shading state behind the node stack (device_core.hpp ColdState): only the kernels that trade registers for waves
   constexpr bool COLD = !LDS && !AA;
+  constexpr bool VOTE = !LDS;  // BVH loops by majority vote (device_core.hpp): scenes traversed from global memory only
   ColdState<COLD> cold;
   cold.bind(smem, P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2, lane);
   // per-pixel sample hand-out state behind the node stack (only allocated for SUB == 4); explicit LDS address space
@@ -602,7 +603,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
         seed_stack<SPILL>(st, H, pred, pred_slot_count, ct);
         if (flags & 1u) {
           if (H.count) atomicAdd(&H.counters[kHoChecked], 1u);
-          const float4 now = first_closest_hit<SPILL>(P, sc, st, up.x, up.y, AA ? H.first_sample[unit] : 0u, ct);
+          const float4 now = first_closest_hit<SPILL, !LDS>(P, sc, st, up.x, up.y, AA ? H.first_sample[unit] : 0u, ct);
           if (same_first(now, H.first[unit])) {  // nothing this unit computes can differ
             active = false;
             replace_ch0_counters<STATS>(H, unit, ct, P.stats);
@@ -1008,7 +1009,7 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
   const uint32_t slot_count = pm & 0x1ffffu;
   seed_stack<SPILL>(st, H, (uint32_t)pred, slot_count, ct);
   if (H.count) atomicAdd(&H.counters[kHoChecked], 1u);
-  const float4 now = first_closest_hit<SPILL>(P, sc, st, up.x, up.y, P.antialiasing ? H.first_sample[unit] : 0u, ct);
+  const float4 now = first_closest_hit<SPILL, !LDS>(P, sc, st, up.x, up.y, P.antialiasing ? H.first_sample[unit] : 0u, ct);
   if (!same_first(now, H.first[unit]))
     handoff_append(H.list_out, H.n_out, H.list_cap, P.status, make_uint4(unit, (uint32_t)pred, slot_count, 0u));
   else
@@ -1049,12 +1050,12 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P) {
   ray_set(ray, f3(P.origin[3 * i], P.origin[3 * i + 1], P.origin[3 * i + 2]),
           f3(P.direction[3 * i], P.direction[3 * i + 1], P.direction[3 * i + 2]));
   if (ANY) {
-    P.occluded[i] = any_hit<ACCEL, true>(P.sc, st, ray, ct) ? 1 : 0;
+    P.occluded[i] = any_hit<ACCEL, true, true>(P.sc, st, ray, ct) ? 1 : 0;
   } else {
     F3 hp = f3(0, 0, 0);
     Geom g;
     float t = FLT_MAX;
-    const int obj = closest_hit<ACCEL, true>(P.sc, st, ray, hp, g, ct, nullptr, &t);
+    const int obj = closest_hit<ACCEL, true, true>(P.sc, st, ray, hp, g, ct, nullptr, &t);
     P.hit_id[i] = obj;
     if (P.t) P.t[i] = obj < 0 ? FLT_MAX : t;
     if (obj < 0) hp = f3(0, 0, 0);

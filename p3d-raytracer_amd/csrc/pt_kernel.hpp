@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
       PT_REGION(2)
       F3 Pn;
       Geom g;
-      const int obj = closest_hit<ACCEL, !LDS>(sc, st, ray, Pn, g, ct);
+      const int obj = closest_hit<ACCEL, !LDS, !LDS>(sc, st, ray, Pn, g, ct);
       PT_REGION(3)
       if (first_ray) {
         first_hit = obj;
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
           F3 hp2;
           Geom g2;
           PT_REGION(5)
-          const int hit2 = closest_hit<ACCEL, !LDS>(sc, st, feeler, hp2, g2, ct);
+          const int hit2 = closest_hit<ACCEL, !LDS, !LDS>(sc, st, feeler, hp2, g2, ct);
           PT_REGION(6)
           if (hit2 >= 0 && hit2 == (int)lobj) {  // main.cpp:472-475
             const double omega = (double)(2 * kPIf) * (1 - cos_a_max);

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
       bool unit_touched = false;
       uint32_t unit_ch0[kCh0Counters] = {0, 0, 0, 0, 0};
       F3 chain_result = f3(0, 0, 0);
-      constexpr bool COLD = false;
+      constexpr bool COLD = false, VOTE = true;
       ColdState<COLD> cold;
 #ifdef P3D_PT_PROFILE
       RegionProf prof; prof.init();  // (instrumented build: the level body marks its regions; only the megakernel reports them)
