@@ -263,6 +263,13 @@ typedef struct p3d_config {
  * so that one rank of an N-rank job renders every N-th stripe of stripe_h rows
  * (stripe_stride = N, y0 = rank * stripe_h); stripe_stride = 1 (or stripe_h = 0)
  * is a plain rectangle.  Output buffers are w*h, local row 0 first.
+ * Under P3D_STACK_LITERAL a tile that is not the whole frame still renders the pixels of the serial frame: for every
+ * row whose predecessor in the frame lies outside the tile the call first finds, among the frame pixels in front of
+ * that row, one whose result provably does not depend on the hit_stack it finds (no primitive of the scene nearer than
+ * its own first hit, ray direction stable under re-normalisation) and renders the pixels from there to the row for
+ * what they leave on the stack.  If no such pixel is found among the 16 nearest candidates the call FAILS with
+ * P3D_ERR_CAPACITY (it never returns a frame that is only probably right); stripes and sub-rectangles of every rank
+ * count are therefore bit-identical to the whole frame, or the caller is told.
  */
 typedef struct p3d_tile {
   int32_t x0, y0, w, h;
