@@ -157,20 +157,13 @@ __device__ __forceinline__ void stage_scene(DevScene& sc, const RenderParams& P,
 // With a schedule (DESIGN.md "Tile schedule") blockIdx order is "most expensive class first":
 // workgroups are dispatched in blockIdx order, so the few long-running tiles start at once and
 // the many short ones fill in behind them instead of the other way round.
-// A schedule entry is a tile index (bits 0..27) and, in bits 28..30, which part of the tile the workgroup renders: 0 = all
-// of it, 1..4 = one 4x4-pixel quadrant (sched_build_kernel splits the tiles that would otherwise be the critical path of
-// a launch with few tiles per wave slot).  sched[0] = number of entries, the entries follow.
-constexpr uint32_t kSchedTileMask = 0x0fffffffu;
-__device__ __forceinline__ bool tile_of_block(const RenderParams& P, uint32_t& tx, uint32_t& ty, uint32_t* part = nullptr) {
+__device__ __forceinline__ bool tile_of_block(const RenderParams& P, uint32_t& tx, uint32_t& ty) {
   const uint32_t b = blockIdx.x;
   const uint32_t n = P.tiles_x * P.tiles_y;
   uint32_t tile;
-  if (part) *part = 0;
   if (P.sched) {
-    if (b >= P.sched[0]) return false;
-    tile = P.sched[1 + b];
-    if (part) *part = tile >> 28;
-    tile &= kSchedTileMask;
+    if (b >= n) return false;
+    tile = P.sched[b];
   } else {
     const uint32_t j = b >> 3;
     tile = ((j / P.xcd_chunk) * 8 + (b & 7u)) * P.xcd_chunk + (j % P.xcd_chunk);
@@ -197,21 +190,11 @@ __device__ __forceinline__ int sched_class(uint32_t cost, float mean) {
   return c < 0 ? 0 : (c >= kSchedClasses ? kSchedClasses - 1 : c);
 }
 
-// `split_slots` (0 = never split): wave slots the launch can fill.  With few tiles per slot a launch is as long as its
-// longest wave.  A tile rendered as four quadrant workgroups of 16 lanes costs kQuarterWork times its time in total, but
-// every quarter is only kQuarterTime of it long (a quarter wave waits for the slowest of 16 lanes per query instead of 64:
-// 100k triangles, whole frame in 4x4 tiles 43.8 ms against 19.3 ms in 8x8 tiles: profiles/r03 experiments).  So splitting
-// the tiles longer than T shortens the longest item to max(T, kQuarterTime * longest) and raises the even-spread time to
-// (total + (kQuarterWork - 1) * cost of the tiles above T) / slots.  T is the fixed point of T = that time: tiles longer
-// than what the launch takes anyway are split, nothing else (and never more than `max_split`: T is raised until it fits).
-constexpr float kQuarterTime = 0.57f, kQuarterWork = 4.0f * 0.57f;
-__global__ void __launch_bounds__(kSchedBuildThreads) sched_build_kernel(const uint32_t* cost, uint32_t n, uint32_t* sched, uint32_t split_slots,
-                                                                         uint32_t max_split, float split_factor) {
-  __shared__ unsigned long long total, above;
-  __shared__ uint32_t cursor[kSchedClasses + 1], n_above;
-  __shared__ float threshold;
+__global__ void __launch_bounds__(kSchedBuildThreads) sched_build_kernel(const uint32_t* cost, uint32_t n, uint32_t* sched) {
+  __shared__ unsigned long long total;
+  __shared__ uint32_t cursor[kSchedClasses];
   if (threadIdx.x == 0) total = 0;
-  if (threadIdx.x <= kSchedClasses) cursor[threadIdx.x] = 0;
+  if (threadIdx.x < kSchedClasses) cursor[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long mine = 0;
   for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) mine += cost[t];
@@ -219,62 +202,18 @@ __global__ void __launch_bounds__(kSchedBuildThreads) sched_build_kernel(const u
   if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
   __syncthreads();
   const float mean = fmaxf((float)total / (float)n, 1.0f);
-  float too_long = 3.0e38f;
-  if (split_slots) {
-    too_long = split_factor * (float)total / (float)split_slots;
-    for (int it = 0; it < 12; ++it) {  // workgroup-uniform
-      if (threadIdx.x == 0) { above = 0; n_above = 0; }
-      __syncthreads();
-      unsigned long long a = 0;
-      uint32_t k = 0;
-      for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads)
-        if ((float)cost[t] > too_long) { a += cost[t]; ++k; }
-      for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); k += __shfl_xor(k, o, 64); }
-      if ((threadIdx.x & 63) == 0 && k) { atomicAdd(&above, a); atomicAdd(&n_above, k); }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        const float spread = split_factor * ((float)total + (kQuarterWork - 1.0f) * (float)above) / (float)split_slots;
-        threshold = n_above > max_split ? too_long * 1.25f : fmaxf(spread, too_long);  // (never lowered: the iteration is monotone)
-      }
-      __syncthreads();
-      too_long = threshold;
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) { above = 0; n_above = 0; }
-    __syncthreads();
-    uint32_t k = 0;
-    for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) k += (float)cost[t] > too_long ? 1u : 0u;
-    for (int o = 32; o > 0; o >>= 1) k += __shfl_xor(k, o, 64);
-    if ((threadIdx.x & 63) == 0 && k) atomicAdd(&n_above, k);
-    __syncthreads();
-    if (n_above > max_split) too_long = 3.0e38f;  // still too many for the grid: no splitting (deterministic either way)
-  }
-  // class kSchedClasses = the tiles that are split (four entries each, first in the order)
-  auto klass = [&](uint32_t t) { return (float)cost[t] > too_long ? kSchedClasses : sched_class(cost[t], mean); };
-  for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) {
-    const int c = klass(t);
-    atomicAdd(&cursor[c], c == kSchedClasses ? 4u : 1u);
-  }
+  for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) atomicAdd(&cursor[sched_class(cost[t], mean)], 1u);
   __syncthreads();
   if (threadIdx.x == 0) {  // class sizes -> first slot of each class, most expensive class first
     uint32_t at = 0;
-    for (int c = kSchedClasses; c >= 0; --c) {
+    for (int c = kSchedClasses - 1; c >= 0; --c) {
       const uint32_t size = cursor[c];
       cursor[c] = at;
       at += size;
     }
-    sched[0] = at;
   }
   __syncthreads();
-  for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) {
-    const int c = klass(t);
-    if (c == kSchedClasses) {
-      const uint32_t at = atomicAdd(&cursor[c], 4u);
-      for (uint32_t q = 0; q < 4; ++q) sched[1 + at + q] = t | ((q + 1) << 28);
-    } else {
-      sched[1 + atomicAdd(&cursor[c], 1u)] = t;
-    }
-  }
+  for (uint32_t t = threadIdx.x; t < n; t += kSchedBuildThreads) sched[atomicAdd(&cursor[sched_class(cost[t], mean)], 1u)] = t;
 }
 
 // One launch instead of a hipMemsetAsync per buffer (each of those is a fill kernel of its own, ~5 us): zeroes up to
@@ -499,9 +438,9 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
   static_assert(SUB == 1 || AA, "four lanes per pixel need more than one sample per pixel");
   static_assert(LIT == 0 || (ACCEL == P3D_ACCEL_BVH && SUB == 1), "only the BVH has a stack to hand on; one lane per pixel");
   extern __shared__ float4 smem[];
-  uint32_t tx = 0, ty = 0, part = 0;
+  uint32_t tx = 0, ty = 0;
   const bool halo_block = LIT == 1 && blockIdx.x >= P.tile_blocks;
-  if (LIT != 2 && !halo_block && !tile_of_block(P, tx, ty, &part)) return;
+  if (LIT != 2 && !halo_block && !tile_of_block(P, tx, ty)) return;
   if (LIT == 2) {  // nothing on the list for this workgroup: leave before the scene is staged
     const uint32_t n0 = __hip_atomic_load(P.hand.n_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((size_t)blockIdx.x * P.hand.lanes >= (n0 > P.hand.list_cap ? P.hand.list_cap : n0)) return;
@@ -580,16 +519,10 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
         up.c = up.r = up.x = up.y = 0; up.halo = true; up.valid = active;
         if (active) up = place_of_unit(P, unit);
       } else {
-        if (SUB == 1 && part) {  // one 4x4 quadrant of an 8x8 tile, 16 lanes (tile_of_block)
-          up.c = (int)((tx << 3) + (((part - 1u) & 1u) << 2) + (px & 3u));
-          up.r = (int)((ty << 3) + (((part - 1u) >> 1) << 2) + (px >> 2));
-          active = px < 16u && up.c < P.w && up.r < P.h;
-        } else {
-          up.c = (int)((tx << tws) + (px & ((1u << tws) - 1u)));
-          up.r = (int)((ty << ths) + (px >> tws));
-          active = px < (1u << (tws + ths)) && up.c < P.w && up.r < P.h;
-        }
+        up.c = (int)((tx << tws) + (px & ((1u << tws) - 1u)));
+        up.r = (int)((ty << ths) + (px >> tws));
         up.halo = false;
+        active = px < (1u << (tws + ths)) && up.c < P.w && up.r < P.h;
         up.valid = active;
         up.x = P.x0 + up.c;
         up.y = image_row(P, up.r);

@@ -70,7 +70,7 @@ struct Scratch {
 // given key runs in frame order and records what every tile cost, the launches after it take
 // the tiles most-expensive-class first.
 struct SchedEntry {
-  uint32_t accel = 0, aa = 0, spp = 0, pt = 0, max_split = 0, tiles_x = 0, tiles_y = 0;  // (tiles: 8x8 or 4x4 pixels, by kernel variant)
+  uint32_t accel = 0, aa = 0, spp = 0, pt = 0, tiles_x = 0, tiles_y = 0;  // (tiles: 8x8 or 4x4 pixels, by kernel variant)
   int32_t max_depth = 0, x0 = 0, y0 = 0, w = 0, h = 0, stripe_h = 0, stripe_stride = 0;
   Scratch cost, sched;
   hipEvent_t ready = nullptr;
@@ -78,7 +78,7 @@ struct SchedEntry {
   uint64_t last_use = 0;
   bool built = false;  // the recording launch and sched_build_kernel were enqueued: `sched` may be used
   bool same_key(const SchedEntry& o) const {
-    return accel == o.accel && aa == o.aa && spp == o.spp && pt == o.pt && max_split == o.max_split && tiles_x == o.tiles_x && tiles_y == o.tiles_y && max_depth == o.max_depth && x0 == o.x0 && y0 == o.y0 &&
+    return accel == o.accel && aa == o.aa && spp == o.spp && pt == o.pt && tiles_x == o.tiles_x && tiles_y == o.tiles_y && max_depth == o.max_depth && x0 == o.x0 && y0 == o.y0 &&
            w == o.w && h == o.h && stripe_h == o.stripe_h && stripe_stride == o.stripe_stride;
   }
 };
@@ -117,8 +117,7 @@ void tile_shape(uint64_t pixels, uint32_t& w, uint32_t& h) {
 }
 constexpr size_t kSchedCacheEntries = 16;
 constexpr uint32_t kSchedMinTiles = 8192;  // LDS-staged scenes: with fewer tiles than ~2 per wave slot nearly all start at once anyway
-constexpr uint32_t kSchedMinTilesL2 = 256;  // scenes traversed from L2: the schedule also decides which tiles are split (sched_build_kernel)
-constexpr uint32_t kMaxSplitTiles = 4096;   // tiles of one launch that may be rendered as four quadrant workgroups
+constexpr uint32_t kSchedMinTilesL2 = 256;  // scenes traversed from L2: a wave lives a millisecond, the order matters from a few hundred tiles
 
 }  // namespace
 
@@ -548,10 +547,10 @@ hipError_t launch_literal(int lit, bool aa, bool lds_scene, bool stats, const Re
 // Looks up the schedule for the launch described by (cfg, P).  Known key: P.sched is set.  New
 // key: P.tile_cost is set so that this launch (in frame order) records the costs, and *fresh
 // points at the entry, to be completed by schedule_finish() right after the launch.
-int schedule_lookup(p3d_scene* s, const p3d_config* cfg, bool pt, uint32_t max_split, RenderParams& P, hipStream_t st, SchedEntry** fresh) {
+int schedule_lookup(p3d_scene* s, const p3d_config* cfg, bool pt, RenderParams& P, hipStream_t st, SchedEntry** fresh) {
   *fresh = nullptr;
   SchedEntry key;
-  key.accel = cfg->accel; key.aa = cfg->antialiasing ? 1 : 0; key.spp = cfg->antialiasing ? cfg->spp_sqrt : 1; key.pt = pt ? 1 : 0; key.max_split = max_split; key.tiles_x = P.tiles_x; key.tiles_y = P.tiles_y;
+  key.accel = cfg->accel; key.aa = cfg->antialiasing ? 1 : 0; key.spp = cfg->antialiasing ? cfg->spp_sqrt : 1; key.pt = pt ? 1 : 0; key.tiles_x = P.tiles_x; key.tiles_y = P.tiles_y;
   key.max_depth = P.max_depth; key.x0 = P.x0; key.y0 = P.y0; key.w = P.w; key.h = P.h;
   key.stripe_h = P.stripe_h; key.stripe_stride = P.stripe_stride;
   for (SchedEntry& c : s->sched)
@@ -574,19 +573,17 @@ int schedule_lookup(p3d_scene* s, const p3d_config* cfg, bool pt, uint32_t max_s
   e->built = false;
   const uint32_t n = P.tiles_x * P.tiles_y;
   if (int rc = e->cost.ensure((size_t)n * sizeof(uint32_t))) return rc;
-  if (int rc = e->sched.ensure(((size_t)n + 3 * (size_t)kMaxSplitTiles + 1) * sizeof(uint32_t))) return rc;  // [0] = entries; a split tile has four
+  if (int rc = e->sched.ensure((size_t)n * sizeof(uint32_t))) return rc;
   if (!e->ready) P3D_HIP(hipEventCreateWithFlags(&e->ready, hipEventDisableTiming));
-  e->accel = key.accel; e->aa = key.aa; e->spp = key.spp; e->pt = key.pt; e->max_split = key.max_split; e->tiles_x = key.tiles_x; e->tiles_y = key.tiles_y; e->max_depth = key.max_depth; e->x0 = key.x0; e->y0 = key.y0;
+  e->accel = key.accel; e->aa = key.aa; e->spp = key.spp; e->pt = key.pt; e->tiles_x = key.tiles_x; e->tiles_y = key.tiles_y; e->max_depth = key.max_depth; e->x0 = key.x0; e->y0 = key.y0;
   e->w = key.w; e->h = key.h; e->stripe_h = key.stripe_h; e->stripe_stride = key.stripe_stride;
   P.tile_cost = (uint32_t*)e->cost.p;
   *fresh = e;
   return P3D_OK;
 }
 
-int schedule_finish(p3d_scene* s, SchedEntry* e, uint32_t n_tiles, hipStream_t st, uint32_t split_slots, uint32_t max_split) {
-  static const float split_factor = [] { const char* v = getenv("P3D_SPLIT_FACTOR"); return v ? (float)atof(v) : 1.0f; }();  // experiments
-  hipLaunchKernelGGL(sched_build_kernel, dim3(1), dim3(kSchedBuildThreads), 0, st, (const uint32_t*)e->cost.p, n_tiles, (uint32_t*)e->sched.p,
-                     split_slots, max_split, split_factor);
+int schedule_finish(p3d_scene* s, SchedEntry* e, uint32_t n_tiles, hipStream_t st) {
+  hipLaunchKernelGGL(sched_build_kernel, dim3(1), dim3(kSchedBuildThreads), 0, st, (const uint32_t*)e->cost.p, n_tiles, (uint32_t*)e->sched.p);
   if (hipError_t err = hipGetLastError(); err != hipSuccess)
     return fail(P3D_ERR_NO_DEVICE, std::string("schedule kernel launch: ") + hipGetErrorString(err));
   P3D_HIP(hipEventRecord(e->ready, st));
@@ -798,20 +795,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   const bool sched_ok = cfg->tile_order == P3D_TILE_ORDER_COST && cfg->max_depth > 0;
   // LITERAL: workgroups behind the tile grid of the first launch render the halo chains (8 chains of 8 pixels per wave)
   const uint32_t halo_blocks_max = literal ? ((uint32_t)tile->h * kHaloChain + kBlock - 1) / kBlock : 0;
-  // Tiles that may be split into quadrant workgroups (sched_build_kernel): only where a wave is as long as the slowest of
-  // its lanes in every query (Whitted without anti-aliasing over a scene traversed from L2) and the launch has fewer than
-  // four 8x8 tiles per wave slot - stripes of a multi-GPU frame, small frames; a big frame packs its long tiles anyway.
-  static const uint32_t wave_slots = [] {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256u * 4u * P3D_WHITTED_GLOBAL_WAVES;
-    return (uint32_t)prop.multiProcessorCount * 4u * P3D_WHITTED_GLOBAL_WAVES;
-  }();
-  static const bool no_split = getenv("P3D_NO_SPLIT") != nullptr;  // experiments
-  const bool split_ok = sched_ok && !no_split && !pt && !lds_scene && !cfg->antialiasing && !sub4 && tpw == 8 && tph == 8 && cfg->chain_launch != P3D_CHAIN_PER_LEVEL;
-  const uint32_t tiles_per_launch = tiles_x * bands_per_launch;
-  const uint32_t max_split = (split_ok && tiles_per_launch < 4 * wave_slots) ? std::min<uint32_t>(kMaxSplitTiles, tiles_per_launch) : 0;
-  const uint32_t max_threads = (blocks_for(tiles_per_launch) + 3 * max_split + halo_blocks_max) * kBlock;
+  const uint32_t max_threads = (blocks_for(tiles_x * bands_per_launch) + halo_blocks_max) * kBlock;
   const size_t tile_units = (size_t)tile->h * ((size_t)tile->w + kHaloChain);  // upper bound of H.n_units
   // per-level launches keep one record per (level, unit); the work-list launches of a LITERAL frame behind them are the
   // megakernel and index [level][launch thread] with up to max_threads threads, whatever the size of the tile
@@ -968,8 +952,8 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       P.tile_cost = nullptr;
       SchedEntry* fresh = nullptr;
       if (pass == 0 && sched_ok && tiles_x * nb >= (lds_scene ? kSchedMinTiles : kSchedMinTilesL2))
-        if (int rc = schedule_lookup(s, cfg, pt, max_split, P, st, &fresh)) return rc;
-      const uint32_t tile_blocks = P.sched ? tiles_x * nb + 3 * max_split : blocks_for(tiles_x * nb);  // scheduled: one workgroup per entry
+        if (int rc = schedule_lookup(s, cfg, pt, P, st, &fresh)) return rc;
+      const uint32_t tile_blocks = blocks_for(tiles_x * nb);
       const uint32_t blocks = tile_blocks + (band0 == 0 ? halo_blocks : 0);  // the halo chains ride on the first launch
       P.tile_blocks = tile_blocks;
       P.level_stride = blocks * kBlock;
@@ -1033,7 +1017,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
         return fail(P3D_ERR_NO_DEVICE, std::string("kernel launch: ") + hipGetErrorString(e));
       }
       if (fresh)
-        if (int rc = schedule_finish(s, fresh, tiles_x * nb, st, max_split ? wave_slots : 0, max_split)) return rc;
+        if (int rc = schedule_finish(s, fresh, tiles_x * nb, st)) return rc;
     }
     if (literal && stats && pass == 0) P3D_HIP(hipEventRecord(s->ev_mid, st));
   }

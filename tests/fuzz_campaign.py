@@ -29,8 +29,8 @@ def main():
     ap.add_argument("--whitted", type=int, default=200)
     ap.add_argument("--pt", type=int, default=40)
     ap.add_argument("--stripes", type=int, default=0,
-                    help="scenes for the stripe / sub-rectangle phase: 192x160 frames (enough tiles for the cost-ordered schedule and "
-                         "the split tiles of scenes traversed from L2), the literal full frame against the oracle, then every stripe "
+                    help="scenes for the stripe / sub-rectangle phase: 192x160 frames (enough tiles for the cost-ordered schedule "
+                         "of scenes traversed from L2), the literal full frame against the oracle, then every stripe "
                          "set of 2 and 4 ranks and a random sub-rectangle against the full frame, each rendered twice (recording "
                          "launch, scheduled launch)")
     ap.add_argument("--start", type=int, default=0)
