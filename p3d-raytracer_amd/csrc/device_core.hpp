@@ -230,8 +230,12 @@ struct DevScene {
 
 // Per-lane traversal stack (bvh.cpp:86 hit_stack, one per pixel instead of one per process:
 // see DESIGN.md "Sequential state").
-//   SPILL == false: the host guarantees that the worst-case height fits the LDS part; every access is a plain
-//                   ds_read_b64 / ds_write_b64 at  base[e * kBlock].
+//   SPILL == false: the host guarantees that the worst-case height fits the LDS part, and that node and leaf-slot indices
+//                   are below 4096 (an LDS-staged scene: at most 26 KB).  An entry is SIX bytes: the distance in a dword
+//                   array (tbase[e * kBlock]) and the descriptor packed into 16 bits (leaf bit, count, 12 index bits) in a
+//                   halfword array behind it (dbase[e * kBlock]).  LDS bytes per workgroup decide how many waves of these
+//                   kernels a CU holds (cfg2: 2 KB of scene + 16 entries; 8-byte entries = 10 KB = 16 workgroups per CU,
+//                   6-byte entries = 20, and the frames-in-flight loop gains a quarter: experiments r03 §13).
 //   SPILL == true : LDS holds a WINDOW of the `cap` (a power of two) most recent entries, entry e in slot e & (cap - 1);
 //                   entries [lo, sp) are in the window, entries [0, lo) in a per-thread column of a global backing
 //                   array.  A push into a full window moves the window's oldest entry out (it sits in the very slot the
@@ -241,8 +245,13 @@ struct DevScene {
 //                   part held the FIRST cap entries: under a leftover of a dozen entries every push and pop of the next
 //                   query went to global memory; 100k triangles 2048x2048: 1.7 GB written per frame, profiles/r03.)
 typedef __attribute__((address_space(3))) unsigned long long lds_uint2;  // explicit LDS pointer to one 8-byte entry: ds_read/write_b64, never flat_*
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
 struct Stack {
-  lds_uint2* base;  // LDS: &stack[lane]; slot s at base[s * kBlock]
+  lds_uint2* base;  // SPILL: &window[lane]; slot s at base[s * kBlock]
+  lds_u16* dbase;   // !SPILL: &desc[lane]; packed descriptor of entry e at dbase[e * kBlock] (LDS address D0 + 2 lane + 128 e) ...
+  uint32_t tfix;    // ... and its distance at LDS address 2 * (that address) + tfix = T0 + 4 lane + 256 e (tfix = T0 - 2 D0 is
+                    // wave-uniform: one per-lane address register for both arrays)
   uint2* spill;     // global backing array (wave-uniform base: scalar registers); entry e of this thread at spill[e * spill_stride + tid]
   uint32_t spill_stride, tid;  // (a 32-bit element offset from a uniform base costs one address register, a per-lane pointer two)
   int sp;
@@ -252,14 +261,38 @@ struct Stack {
 __device__ __forceinline__ lds_uint2* lds_stack_ptr(float4* smem_base, size_t float4_offset, uint32_t lane) {
   return (lds_uint2*)(reinterpret_cast<unsigned long long*>(smem_base + float4_offset)) + lane;
 }
+// LDS of one workgroup's node stacks, in float4 units
+__host__ __device__ constexpr uint32_t stack_lds_f4(bool spill, uint32_t cap) { return cap * kBlock * (spill ? 8u : 6u) / 16u; }
+// the 16-bit form of a descriptor (indices < 4096) and back
+__device__ __forceinline__ uint32_t pack_desc16(uint32_t desc) { return desc | (desc >> 16); }  // low half (bits 27..12 are zero: the flags land in bits 15..12)
+__device__ __forceinline__ uint32_t unpack_desc16(uint32_t pk) { return ((pk & 0xf000u) << 16) | (pk & 0x0fffu); }
 __device__ __forceinline__ void stack_clear(Stack& s) { s.sp = 0; s.lo = 0; }
+__device__ __forceinline__ lds_u32* stack_t_of(const Stack& s, const lds_u16* d) {  // (!SPILL) where the distance of the entry with descriptor *d lives
+  return (lds_u32*)(uintptr_t)(2u * (uint32_t)(uintptr_t)d + s.tfix);
+}
+// the stacks of a workgroup start `float4_offset` float4s into its LDS; `cap` entries per lane
+__device__ __forceinline__ void stack_bind(Stack& s, float4* smem_base, size_t float4_offset, uint32_t lane, int cap, uint2* backing,
+                                           uint32_t backing_stride, uint32_t tid) {
+  s.base = lds_stack_ptr(smem_base, float4_offset, lane);
+  lds_u32* t0 = (lds_u32*)(reinterpret_cast<uint32_t*>(smem_base + float4_offset));  // distances first, descriptors behind them
+  lds_u16* d0 = (lds_u16*)(t0 + (size_t)cap * kBlock);
+  s.dbase = d0 + lane;
+  s.tfix = (uint32_t)(uintptr_t)t0 - 2u * (uint32_t)(uintptr_t)d0;
+  s.spill = backing;
+  s.spill_stride = backing_stride;
+  s.tid = tid;
+  s.cap = cap;
+  stack_clear(s);
+}
 __device__ __forceinline__ uint2 unpack_entry(unsigned long long v) { return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
 template <bool SPILL, class CT>
 __device__ __forceinline__ void push(Stack& s, uint32_t node, float t, CT& ct) {
-  const unsigned long long e = (unsigned long long)node | ((unsigned long long)__float_as_uint(t) << 32);
   if (!SPILL) {
-    *(s.base + s.sp * kBlock) = e;
+    lds_u16* d = s.dbase + s.sp * kBlock;
+    *d = (uint16_t)pack_desc16(node);
+    *stack_t_of(s, d) = __float_as_uint(t);
   } else {
+    const unsigned long long e = (unsigned long long)node | ((unsigned long long)__float_as_uint(t) << 32);
     lds_uint2* p = s.base + (s.sp & (s.cap - 1)) * kBlock;
     if (s.sp - s.lo == s.cap) {  // window full: its oldest entry lives in this slot and moves to the backing array
       s.spill[(uint32_t)s.lo * s.spill_stride + s.tid] = unpack_entry(*p);
@@ -278,7 +311,8 @@ template <bool SPILL>
 __device__ __forceinline__ uint2 stack_read(const Stack& s, int i) {
   uint2 e;
   if (!SPILL) {
-    e = unpack_entry(*(s.base + i * kBlock));
+    const lds_u16* d = s.dbase + i * kBlock;
+    e = make_uint2(unpack_desc16(*d), *stack_t_of(s, d));
   } else if (i >= s.lo) {
     e = unpack_entry(*(s.base + (i & (s.cap - 1)) * kBlock));
     asm volatile("" : "+v"(e.x), "+v"(e.y));  // keep the two address spaces apart (no flat_load)
@@ -509,17 +543,25 @@ __device__ __forceinline__ uint32_t pop_closer(Stack& st, float tmin) {
 // iff t0 = max(near products) < 0 and t1 = min(far products) > 0: two compares instead of the twelve of AABB::isInside
 // (boundingBox.cpp:39-42), same truth value (boxes with min <= max: what a BVH build produces; a descriptor with an inverted
 // box makes the scene take the slow path, p3d_scene_create).  Otherwise the test as the reference writes it.
+// May the slab tests of this wave use v_max3 / v_min3 (no NaN can arise)?  Wave-uniform.  FASTIN: ... and may bvh_closest take
+// isInside from the slab interval (needs boxes with min <= max as well: DevScene::odd_boxes)?  Only the loops that wait
+// on memory per visit use that form (VOTE, scenes traversed from global memory); for LDS-staged scenes the extra scalar
+// state costs more than the ten compares it saves (cfg2 frames-in-flight loop: 3 %, experiments r03 §13).
+template <bool FASTIN>
+__device__ __forceinline__ bool slab_fast_path(const DevScene& sc, const RayS& ray) {
+  return FASTIN ? (!sc.odd_boxes && !__any(ray.odd_inv)) : !__any(ray.odd_inv);
+}
 #define P3D_CLOSEST_DESCEND_STEP \
   {\
       const uint32_t index = desc_index(desc);\
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);\
       float l_t, r_t;\
       ct.add(kNodeTests, 2);\
-      const bool fin = (!sc.odd_boxes && !__any(ray.odd_inv));\
+      const bool fin = slab_fast_path<FASTIN>(sc, ray);\
       float l_t0, l_t1, r_t0, r_t1;\
       const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin, &l_t0, &l_t1);\
       const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin, &r_t0, &r_t1);\
-      if (fin) {\
+      if (FASTIN && fin) {\
         if (l_t0 < 0 && l_t1 > 0) l_t = 0;\
         if (r_t0 < 0 && r_t1 > 0) r_t = 0;\
       } else {\
@@ -551,11 +593,12 @@ __device__ __forceinline__ uint32_t pop_closer(Stack& st, float tmin) {
 template <bool SPILL, class CT, bool VOTE = SPILL>
 __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_point, Geom& hit_geom, CT& ct,
                            bool* root_passed = nullptr, float* t_out = nullptr, RayS* final_ray = nullptr) {
+  constexpr bool FASTIN = VOTE;
   float tmp, tmin = FLT_MAX;
   int hit = -1;
   const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
-  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, (!sc.odd_boxes && !__any(ray.odd_inv)))) return -1;  // stale entries stay (Q2)
+  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, slab_fast_path<FASTIN>(sc, ray))) return -1;  // stale entries stay (Q2)
   if (root_passed) *root_passed = true;
   // The traversal state is ONE word: the descriptor of the node the lane stands on, or kDescDone (leaf bit set, so
   // that a finished lane also falls out of the descend loop): fewer lane masks for the compiler to carry round the loops.
@@ -597,7 +640,7 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
       const NodeRec l = load_node(sc.nodes, index), r = load_node(sc.nodes, index + 1);\
       float l_t, r_t;\
       ct.add(kNodeTests, 2);\
-      const bool fin = (!sc.odd_boxes && !__any(ray.odd_inv));\
+      const bool fin = slab_fast_path<FASTIN>(sc, ray);\
       const bool l_hit = aabb_intercepts(xyz(l.lo), xyz(l.hi), ray, l_t, fin);\
       const bool r_hit = aabb_intercepts(xyz(r.lo), xyz(r.hi), ray, r_t, fin);\
       const uint32_t ld = __float_as_uint(l.lo.w), rd = __float_as_uint(r.lo.w);\
@@ -625,10 +668,11 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
   }
 template <bool SPILL, class CT, bool VOTE = SPILL>
 __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
+  constexpr bool FASTIN = VOTE;
   float tmp;
   const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
-  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, (!sc.odd_boxes && !__any(ray.odd_inv)))) return false;
+  if (!aabb_intercepts(xyz(root.lo), xyz(root.hi), ray, tmp, slab_fast_path<FASTIN>(sc, ray))) return false;
   // state word as in bvh_closest, with a second end state: kDescHit = a primitive was hit (no flag to carry round the loops)
   uint32_t desc = __float_as_uint(root.lo.w);
   // bvh.cpp:329-338: pop all, continue from the first-pushed entry; nothing left = done

@@ -52,20 +52,32 @@ __device__ unsigned long long* g_timeline = nullptr;
 #ifdef P3D_PT_PROFILE  // debug builds only: wave-time, entries and active lanes per region of a kernel's loop
 __device__ unsigned long long* g_pt_prof = nullptr;
 constexpr int kProfRegions = 12;
+// The clock belongs to the wave, not to a lane: whichever lanes reach a marker, the time since the previous marker
+// (reached by any lanes) was spent executing the region that marker opened — divergent paths run one after the other.
+struct RegionProfShared { unsigned long long acc[kProfRegions], lanes[kProfRegions], iters[kProfRegions], last; int cur; };
 struct RegionProf {
-  unsigned long long acc[kProfRegions], lanes[kProfRegions], iters[kProfRegions], last;
-  int cur;
-  __device__ void init() { for (int i = 0; i < kProfRegions; ++i) acc[i] = lanes[i] = iters[i] = 0; cur = 0; last = __builtin_readcyclecounter(); }
+  volatile RegionProfShared* s;
+  __device__ void init() {
+    __shared__ RegionProfShared sh;  // one wave per workgroup
+    s = &sh;
+    if (__ffsll((unsigned long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63)) {
+      for (int i = 0; i < kProfRegions; ++i) s->acc[i] = s->lanes[i] = s->iters[i] = 0;
+      s->cur = 0; s->last = __builtin_readcyclecounter();
+    }
+  }
   __device__ void enter(int r) {
     __builtin_amdgcn_s_waitcnt(0);  // outstanding loads belong to the region that issued them
-    const unsigned long long now = __builtin_readcyclecounter();
-    acc[cur] += now - last; last = now; cur = r;
-    lanes[r] += __popcll(__ballot(1)); iters[r] += 1;
+    const unsigned long long now = __builtin_readcyclecounter(), m = __ballot(1);
+    if (__ffsll(m) - 1 == (int)(threadIdx.x & 63)) {
+      s->acc[s->cur] += now - s->last; s->last = now; s->cur = r;
+      s->lanes[r] += __popcll(m); s->iters[r] += 1;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
   }
   __device__ void flush() {
     if (g_pt_prof && __ffsll((unsigned long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63))
       for (int i = 0; i < kProfRegions; ++i) {
-        atomicAdd(&g_pt_prof[3 * i], acc[i]); atomicAdd(&g_pt_prof[3 * i + 1], lanes[i]); atomicAdd(&g_pt_prof[3 * i + 2], iters[i]);
+        atomicAdd(&g_pt_prof[3 * i], s->acc[i]); atomicAdd(&g_pt_prof[3 * i + 1], s->lanes[i]); atomicAdd(&g_pt_prof[3 * i + 2], s->iters[i]);
       }
   }
 };
@@ -77,7 +89,10 @@ struct RegionProf {
 struct RenderParams {
   DevScene sc;
   const float4* blob;   // all float4 scene arrays, contiguous (for the LDS staging copy)
-  uint32_t blob_f4;     // size of blob in float4
+  uint32_t blob_f4;     // float4s of blob staged in LDS (= lds_scene_f4 when the scene is staged): the arrays a kernel of this
+                        // launch reads in its loops, without the alignment pad in front and - Whitted over the BVH, which only
+                        // reads the BVH-ordered copy - without the object-order geometry at the end
+  uint32_t stage_lo;    // first staged float4 of blob
   // byte offsets (in float4) of the arrays inside blob, same order as DevScene
   uint32_t off_nodes, off_bgeom, off_ogeom, off_normals, off_mats, off_lights;
   // options (p3d_config)
@@ -136,14 +151,14 @@ struct RenderParams {
 template <bool LDS>
 __device__ __forceinline__ void stage_scene(DevScene& sc, const RenderParams& P, float4* smem) {
   if (LDS) {
-    for (uint32_t i = threadIdx.x; i < P.blob_f4; i += kBlock) smem[i] = P.blob[i];
+    for (uint32_t i = threadIdx.x; i < P.blob_f4; i += kBlock) smem[i] = P.blob[P.stage_lo + i];
     __syncthreads();
-    sc.nodes = smem + P.off_nodes;
-    sc.bgeom = smem + P.off_bgeom;
-    sc.ogeom = smem + P.off_ogeom;
-    sc.normals = smem + P.off_normals;
-    sc.mats = smem + P.off_mats;
-    sc.lights = smem + P.off_lights;
+    sc.nodes = smem + (P.off_nodes - P.stage_lo);
+    sc.bgeom = smem + (P.off_bgeom - P.stage_lo);
+    sc.normals = smem + (P.off_normals - P.stage_lo);
+    sc.mats = smem + (P.off_mats - P.stage_lo);
+    sc.lights = smem + (P.off_lights - P.stage_lo);
+    if (P.off_ogeom - P.stage_lo < P.blob_f4) sc.ogeom = smem + (P.off_ogeom - P.stage_lo);  // (otherwise: stays in global memory)
   }
 }
 
@@ -457,20 +472,15 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
   Counters<STATS> ct;
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
-  st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
-  st.spill = P.spill;
-  st.tid = blockIdx.x * kBlock + lane;
-  st.spill_stride = P.level_stride;
-  stack_clear(st);
-  st.cap = P.stack_cap;
+  stack_bind(st, smem, P.lds_scene_f4, lane, P.stack_cap, P.spill, P.level_stride, blockIdx.x * kBlock + lane);
   const uint32_t gid = blockIdx.x * kBlock + lane;
   // cold shading state behind the node stack (device_core.hpp ColdState): only the kernels that trade registers for waves
   constexpr bool COLD = !LDS && !AA;
   constexpr bool VOTE = !LDS;  // BVH loops by majority vote (device_core.hpp): scenes traversed from global memory only
   ColdState<COLD> cold;
-  cold.bind(smem, P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2, lane);
+  cold.bind(smem, P.lds_scene_f4 + stack_lds_f4(SPILL, P.stack_cap), lane);
   // per-pixel sample hand-out state behind the node stack (only allocated for SUB == 4); explicit LDS address space
-  LdsPtPixelShared& shared = *(LdsPtPixelShared*)(smem + P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2);
+  LdsPtPixelShared& shared = *(LdsPtPixelShared*)(smem + P.lds_scene_f4 + stack_lds_f4(SPILL, P.stack_cap));
   if (SUB == 4 && sub == 0) {
     shared.next_start[px] = 0;
     shared.next_add[px] = 0;
@@ -564,7 +574,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
         RegionProf prof; prof.init();
 #endif
         // one sample per pixel: the hit ID goes to memory when it is known instead of riding through the whole chain in a register
-        constexpr bool EARLY_HIT = !AA;
+        constexpr bool EARLY_HIT = !AA && !LDS;  // (kernels that trade registers for waves; over an LDS-staged scene the extra store only costs)
         if (EARLY_HIT && P.hit_id && !(LIT != 0 && up.halo)) P.hit_id[(size_t)r * P.w + c] = -1;  // a primary ray that is never traced (none: every sample is) would leave -1
 #define P3D_FIRST_HIT(obj)                                                                                   \
   do {                                                                                                       \
@@ -851,12 +861,7 @@ __global__ void __launch_bounds__(kHaloFindThreads) halo_find_kernel(const Rende
         pixel_first_touching_ray(P, root, pix, ray);  // (every thread: the same ray)
         if (wave == 0) {
           Stack st;
-          st.base = lds_stack_ptr(smem, 0, lane);
-          st.spill = P.spill;
-          st.tid = blockIdx.x * kBlock + lane;
-          st.spill_stride = backing_stride;
-          st.cap = (int)window;
-          stack_clear(st);
+          stack_bind(st, smem, 0, lane, (int)window, P.spill, backing_stride, blockIdx.x * kBlock + lane);
           F3 hp;
           Geom g;
           float tmin = FLT_MAX;
@@ -932,12 +937,7 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
   Counters<STATS> ct;
   ct.clear();
   Stack st;
-  st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
-  st.spill = P.spill;
-  st.tid = blockIdx.x * kBlock + lane;
-  st.spill_stride = P.level_stride;
-  stack_clear(st);
-  st.cap = P.stack_cap;
+  stack_bind(st, smem, P.lds_scene_f4, lane, P.stack_cap, P.spill, P.level_stride, blockIdx.x * kBlock + lane);
   const UnitPlace up = place_of_unit(P, unit);
   const uint32_t slot_count = pm & 0x1ffffu;
   seed_stack<SPILL>(st, H, (uint32_t)pred, slot_count, ct);
@@ -971,12 +971,7 @@ __global__ void __launch_bounds__(kBlock) trace_kernel(const TraceParams P) {
   extern __shared__ float4 smem[];
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   Stack st;
-  st.base = lds_stack_ptr(smem, 0, threadIdx.x);
-  st.spill = P.spill;
-  st.tid = i;
-  st.spill_stride = P.spill_stride;
-  stack_clear(st);
-  st.cap = P.stack_cap;
+  stack_bind(st, smem, 0, threadIdx.x, P.stack_cap, P.spill, P.spill_stride, i);
   if (i >= P.n) return;
   Counters<false> ct;
   RayS ray;

@@ -38,6 +38,7 @@ constexpr uint32_t kWhittedSub4MinSppSqrt = P3D_WHITTED_SUB4_MIN_SPP_SQRT;
 constexpr uint32_t kPtSub4MinSppSqrt = P3D_PT_SUB4_MIN_SPP_SQRT;  // from 16 samples per pixel: 4 lanes per pixel
 constexpr uint32_t kLdsSceneLimitBytesPt = 16 * 1024;  // same for the path tracer (not re-tuned: its packaged scenes are 1-2 KB)
 constexpr uint32_t kLdsSceneLimitBytes = 26 * 1024;  // stage the scene in LDS up to this size
+static_assert(kLdsSceneLimitBytes / 32 < 4096 && kLdsSceneLimitBytesPt / 32 < 4096, "the 6-byte stack entries of LDS-staged scenes keep 12 index bits (device_core.hpp Stack)");
 // A frame is rendered by as few launches as the per-thread scratch (level records + stack spill)
 // allows: every launch ends with a tail of partly idle CUs (2048x2048, 100k triangles: 30.3 ms in
 // two launches, 28.1 ms in one).
@@ -322,12 +323,6 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
     geom_of(d->bvh_prim_index[i], g);
     blob.insert(blob.end(), g, g + 3);
   }
-  s->off_ogeom = (uint32_t)blob.size();
-  for (uint32_t i = 0; i < d->n_prims; ++i) {
-    float4 g[3];
-    geom_of(i, g);
-    blob.insert(blob.end(), g, g + 3);
-  }
   s->off_normals = (uint32_t)blob.size();
   for (uint32_t i = 0; i < d->n_prims; ++i) blob.push_back(make_float4(d->prims[i].n[0], d->prims[i].n[1], d->prims[i].n[2], 0.f));
   s->off_mats = (uint32_t)blob.size();
@@ -343,6 +338,14 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
     const p3d_light& l = d->lights[i];
     blob.push_back(make_float4(l.position[0], l.position[1], l.position[2], 0.f));
     blob.push_back(make_float4(l.color[0], l.color[1], l.color[2], 0.f));
+  }
+  // object-order geometry last: the kernels that walk the BVH read the BVH-ordered copy only, and an LDS-staged launch of
+  // theirs leaves this array out (stage range, p3d_render_tile_device)
+  s->off_ogeom = (uint32_t)blob.size();
+  for (uint32_t i = 0; i < d->n_prims; ++i) {
+    float4 g[3];
+    geom_of(i, g);
+    blob.insert(blob.end(), g, g + 3);
   }
   if (blob.empty()) blob.push_back(make_float4(0, 0, 0, 0));
   s->blob_f4 = (uint32_t)blob.size();
@@ -702,8 +705,12 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   // whole stack lives in LDS too (kernel without a spill path); otherwise (Whitted, several lights, deeper tree)
   // the staged scene is combined with the spilling stack: balls_medium 0.48 -> 0.40 ms, balls_box 0.42 -> 0.32 ms,
   // 96 / 128 random objects 0.49 -> 0.42 / 0.75 -> 0.66 ms against traversing those 14-25 KB from L2.
-  const bool lds_scene = (size_t)s->blob_f4 * sizeof(float4) <= (pt ? kLdsSceneLimitBytesPt : kLdsSceneLimitBytes) && (bound <= 24 || !pt);
-  const bool lds_spill = lds_scene && !pt && (bound > 24 || (size_t)s->blob_f4 * sizeof(float4) + (size_t)bound * kBlock * sizeof(uint2) > 20 * 1024);
+  // (staged: blob[off_nodes, stage_hi) - not the alignment pad in front of the nodes, and not the object-order geometry when
+  // the kernel walks the BVH and is not the path tracer, which looks its emitters up by object)
+  const uint32_t stage_lo = s->off_nodes, stage_hi = (cfg->accel == P3D_ACCEL_BVH && !pt) ? s->off_ogeom : s->blob_f4;
+  const size_t stage_bytes = (size_t)(stage_hi - stage_lo) * sizeof(float4);
+  const bool lds_scene = stage_bytes <= (pt ? kLdsSceneLimitBytesPt : kLdsSceneLimitBytes) && (bound <= 24 || !pt);
+  const bool lds_spill = lds_scene && !pt && (bound > 24 || stage_bytes + (size_t)stack_lds_f4(false, bound) * sizeof(float4) > 20 * 1024);
   // Spilling stack (scenes traversed from L2; LDS-staged scenes whose worst case does not fit): LDS holds a window of the
   // most recent `window` entries (a power of two, device_core.hpp "Stack"), older entries sink into a per-thread column of
   // a global backing array.  8 entries = 4 KB per wave: all 32 wave slots of a CU fit its 160 KB of LDS.
@@ -719,7 +726,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
 
   RenderParams P{};
   P.sc = s->dev;
-  P.blob = s->d_blob; P.blob_f4 = s->blob_f4;
+  P.blob = s->d_blob; P.blob_f4 = lds_scene ? stage_hi - stage_lo : 0; P.stage_lo = stage_lo;
   P.off_nodes = s->off_nodes; P.off_bgeom = s->off_bgeom; P.off_ogeom = s->off_ogeom;
   P.off_normals = s->off_normals; P.off_mats = s->off_mats; P.off_lights = s->off_lights;
   P.max_depth = cfg->max_depth; P.spp_sqrt = cfg->spp_sqrt; P.antialiasing = cfg->antialiasing;
@@ -733,7 +740,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   P.debug_trip_bound = g_debug_trip_bound;
   P.stack_cap = (int32_t)cap;
   P.stack_spills = lds_spill ? 1u : 0u;
-  P.lds_scene_f4 = lds_scene ? s->blob_f4 : 0;
+  P.lds_scene_f4 = P.blob_f4;
   // path tracer with >= 16 samples per pixel: four lanes per pixel, 4x4-pixel tiles (pt_kernel SUB = 4)
   // ... and anti-aliased Whitted launches with >= 4 samples per pixel over a scene traversed from L2 (whitted_kernel SUB = 4),
   // unless the samples of a pixel have to hand the stack to each other in order (LITERAL)
@@ -751,7 +758,8 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   const uint32_t tp = tph;  // rows per tile band
   P.tile_w_shift = tpw == 8 ? 3 : 2;
   P.tile_h_shift = tph == 8 ? 3 : 2;
-  const size_t lds_bytes = (size_t)P.lds_scene_f4 * sizeof(float4) + (size_t)cap * kBlock * sizeof(uint2) +
+  // (entry size: what the kernel's SPILL parameter says - every kernel over a scene that is not staged, and lds_spill)
+  const size_t lds_bytes = (size_t)P.lds_scene_f4 * sizeof(float4) + (size_t)stack_lds_f4(!lds_scene || lds_spill, cap) * sizeof(float4) +
                            (sub4 ? sizeof(PtPixelShared) : 0) + (cold_lds ? (size_t)kColdDwords * kBlock * sizeof(float) : 0);
 
   // rows per launch: whole 8-row tile bands, at most kMaxLaunchThreads threads

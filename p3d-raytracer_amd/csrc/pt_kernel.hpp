@@ -82,19 +82,14 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
   Counters<STATS> ct;
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
-  st.base = lds_stack_ptr(smem, P.lds_scene_f4, lane);
-  st.spill = P.spill;
-  st.tid = blockIdx.x * kBlock + lane;
-  st.spill_stride = P.level_stride;
-  stack_clear(st);
-  st.cap = P.stack_cap;
+  stack_bind(st, smem, P.lds_scene_f4, lane, P.stack_cap, P.spill, P.level_stride, blockIdx.x * kBlock + lane);
   Pending pend;
   pend.base = P.levels + (blockIdx.x * kBlock + lane);
   pend.stride = P.level_stride;
   pend.n = 0;
   // after the node stack (only allocated for SUB == 4); explicit LDS address space: a generic
   // pointer would compile to flat_load/flat_store, which are not ordered with the ds_* traffic
-  LdsPtPixelShared& shared = *(LdsPtPixelShared*)(smem + P.lds_scene_f4 + (size_t)P.stack_cap * kBlock / 2);
+  LdsPtPixelShared& shared = *(LdsPtPixelShared*)(smem + P.lds_scene_f4 + stack_lds_f4(!LDS, P.stack_cap));
   if (SUB == 4 && sub == 0) {
     shared.next_start[px] = 0;
     shared.next_add[px] = 0;

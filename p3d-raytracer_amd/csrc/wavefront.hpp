@@ -64,12 +64,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
   Counters<STATS> ct;
   if (STATS) reinterpret_cast<Counters<true>&>(ct).clear();
   Stack st;
-  st.base = lds_stack_ptr(smem, 0, lane);
-  st.spill = P.spill;
-  st.tid = gid;
-  st.spill_stride = P.level_stride;
-  stack_clear(st);
-  st.cap = P.stack_cap;
+  stack_bind(st, smem, 0, lane, P.stack_cap, P.spill, P.level_stride, gid);
   const uint32_t seg = blockIdx.x & (kWfSegments - 1);
   uint32_t tx = 0, ty = 0;
   const bool halo_block = level == 0 && LIT == 1 && blockIdx.x >= P.tile_blocks;
