@@ -148,7 +148,8 @@ struct RenderParams {
 };
 
 // LDS map of one workgroup:  [ staged scene (lds_scene_f4 float4) | node stack (cap * 64 * 8 B) | per-pixel sample ring (PT, 4 lanes per pixel) ]
-template <bool LDS>
+// OBJECTS: the launch stages the object-order geometry too (every kernel but Whitted over the BVH; the host's stage range)
+template <bool LDS, bool OBJECTS>
 __device__ __forceinline__ void stage_scene(DevScene& sc, const RenderParams& P, float4* smem) {
   if (LDS) {
     for (uint32_t i = threadIdx.x; i < P.blob_f4; i += kBlock) smem[i] = P.blob[P.stage_lo + i];
@@ -158,7 +159,7 @@ __device__ __forceinline__ void stage_scene(DevScene& sc, const RenderParams& P,
     sc.normals = smem + (P.off_normals - P.stage_lo);
     sc.mats = smem + (P.off_mats - P.stage_lo);
     sc.lights = smem + (P.off_lights - P.stage_lo);
-    if (P.off_ogeom - P.stage_lo < P.blob_f4) sc.ogeom = smem + (P.off_ogeom - P.stage_lo);  // (otherwise: stays in global memory)
+    if (OBJECTS) sc.ogeom = smem + (P.off_ogeom - P.stage_lo);  // (otherwise: stays in global memory)
   }
 }
 
@@ -463,7 +464,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
   P3D_TL_BEGIN()
   const unsigned long long t_begin = (LIT != 2 && P.tile_cost) ? wall_clock64() : 0;
   DevScene sc = P.sc;
-  stage_scene<LDS>(sc, P, smem);
+  stage_scene<LDS, ACCEL != P3D_ACCEL_BVH>(sc, P, smem);
 
   const uint32_t lane = threadIdx.x;
   const uint32_t tws = SUB == 4 ? 2u : P.tile_w_shift, ths = SUB == 4 ? 2u : P.tile_h_shift;  // tile = (1 << tws) x (1 << ths) pixels
@@ -932,7 +933,7 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
   const bool need = (pm & 0xffffu) != 0;  // otherwise the predecessor left nothing: pass 1's empty stack was right
   if (__ballot(need) == 0) return;
   DevScene sc = P.sc;
-  stage_scene<LDS>(sc, P, smem);
+  stage_scene<LDS, false>(sc, P, smem);  // (the hand-off exists for the BVH only)
   if (!need) return;
   Counters<STATS> ct;
   ct.clear();

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
   P3D_TL_BEGIN()
   const unsigned long long t_begin = P.tile_cost ? wall_clock64() : 0;
   DevScene sc = P.sc;
-  stage_scene<LDS>(sc, P, smem);
+  stage_scene<LDS, true>(sc, P, smem);
 
   const uint32_t lane = threadIdx.x;
   constexpr int TP = SUB == 4 ? 4 : 8;                       // tile edge in pixels
