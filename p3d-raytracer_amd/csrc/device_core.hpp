@@ -244,6 +244,12 @@ struct DevScene {
 //                   leftovers of earlier any-hit queries (Q2) under a deep closest-hit traversal.  (Until round 3 the LDS
 //                   part held the FIRST cap entries: under a leftover of a dozen entries every push and pop of the next
 //                   query went to global memory; 100k triangles 2048x2048: 1.7 GB written per frame, profiles/r03.)
+// The SPILL parameter of everything below: bool-compatible (false = kStackLds6, true = kStackWindow), plus a third form
+constexpr int kStackLds6 = 0;    // whole stack in LDS, six-byte entries
+constexpr int kStackWindow = 1;  // LDS window + global backing array, eight-byte entries
+constexpr int kStackLds8 = 2;    // whole stack in LDS, eight-byte entries: kernels whose registers, not their LDS, set how many
+                                 // waves a CU holds (the path tracer: 128 VGPRs) - one ds_*_b64 per access instead of two
+                                 // narrower ones and the packing (Cornell box 1024x1024 256 spp: 144.2 -> 139.8 ms)
 typedef __attribute__((address_space(3))) unsigned long long lds_uint2;  // explicit LDS pointer to one 8-byte entry: ds_read/write_b64, never flat_*
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
@@ -262,7 +268,7 @@ __device__ __forceinline__ lds_uint2* lds_stack_ptr(float4* smem_base, size_t fl
   return (lds_uint2*)(reinterpret_cast<unsigned long long*>(smem_base + float4_offset)) + lane;
 }
 // LDS of one workgroup's node stacks, in float4 units
-__host__ __device__ constexpr uint32_t stack_lds_f4(bool spill, uint32_t cap) { return cap * kBlock * (spill ? 8u : 6u) / 16u; }
+__host__ __device__ constexpr uint32_t stack_lds_f4(int mode, uint32_t cap) { return cap * kBlock * (mode == kStackLds6 ? 6u : 8u) / 16u; }
 // the 16-bit form of a descriptor (indices < 4096) and back
 __device__ __forceinline__ uint32_t pack_desc16(uint32_t desc) { return desc | (desc >> 16); }  // low half (bits 27..12 are zero: the flags land in bits 15..12)
 __device__ __forceinline__ uint32_t unpack_desc16(uint32_t pk) { return ((pk & 0xf000u) << 16) | (pk & 0x0fffu); }
@@ -285,12 +291,14 @@ __device__ __forceinline__ void stack_bind(Stack& s, float4* smem_base, size_t f
   stack_clear(s);
 }
 __device__ __forceinline__ uint2 unpack_entry(unsigned long long v) { return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); }
-template <bool SPILL, class CT>
+template <int SPILL, class CT>
 __device__ __forceinline__ void push(Stack& s, uint32_t node, float t, CT& ct) {
-  if (!SPILL) {
+  if (SPILL == kStackLds6) {
     lds_u16* d = s.dbase + s.sp * kBlock;
     *d = (uint16_t)pack_desc16(node);
     *stack_t_of(s, d) = __float_as_uint(t);
+  } else if (SPILL == kStackLds8) {
+    *(s.base + s.sp * kBlock) = (unsigned long long)node | ((unsigned long long)__float_as_uint(t) << 32);
   } else {
     const unsigned long long e = (unsigned long long)node | ((unsigned long long)__float_as_uint(t) << 32);
     lds_uint2* p = s.base + (s.sp & (s.cap - 1)) * kBlock;
@@ -307,12 +315,14 @@ __device__ __forceinline__ void push(Stack& s, uint32_t node, float t, CT& ct) {
   ct.stack_depth(s.sp);
 }
 // entry i < sp, wherever it lives; the stack is not changed
-template <bool SPILL>
+template <int SPILL>
 __device__ __forceinline__ uint2 stack_read(const Stack& s, int i) {
   uint2 e;
-  if (!SPILL) {
+  if (SPILL == kStackLds6) {
     const lds_u16* d = s.dbase + i * kBlock;
     e = make_uint2(unpack_desc16(*d), *stack_t_of(s, d));
+  } else if (SPILL == kStackLds8) {
+    e = unpack_entry(*(s.base + i * kBlock));
   } else if (i >= s.lo) {
     e = unpack_entry(*(s.base + (i & (s.cap - 1)) * kBlock));
     asm volatile("" : "+v"(e.x), "+v"(e.y));  // keep the two address spaces apart (no flat_load)
@@ -323,11 +333,11 @@ __device__ __forceinline__ uint2 stack_read(const Stack& s, int i) {
   return e;
 }
 // --sp and the entry that was on top
-template <bool SPILL>
+template <int SPILL>
 __device__ __forceinline__ uint2 pop(Stack& s) {
   --s.sp;
   const uint2 e = stack_read<SPILL>(s, s.sp);
-  if (SPILL && s.sp < s.lo) s.lo = s.sp;  // popped below the window: the window is empty now
+  if (SPILL == kStackWindow && s.sp < s.lo) s.lo = s.sp;  // popped below the window: the window is empty now
   return e;
 }
 
@@ -516,7 +526,7 @@ __device__ __forceinline__ NodeRec load_node(const float4* nodes, uint32_t i) {
 
 // bvh.cpp:256-265: pop until an entry is nearer than the best hit; kDescDone = stack exhausted.  One loop condition
 // (`more`) and no exit from the middle: the compiler's loop then needs one lane mask instead of three.
-template <bool SPILL>
+template <int SPILL>
 __device__ __forceinline__ uint32_t pop_closer(Stack& st, float tmin) {
   uint32_t desc = kDescDone;
   bool more = st.sp > 0;
@@ -590,10 +600,10 @@ __device__ __forceinline__ bool slab_fast_path(const DevScene& sc, const RayS& r
       }\
       desc = pop_closer<SPILL>(st, tmin);\
   }
-template <bool SPILL, class CT, bool VOTE = SPILL>
+template <int SPILL, class CT, bool VOTE = (SPILL == kStackWindow), bool FASTIN_ = VOTE>
 __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_point, Geom& hit_geom, CT& ct,
                            bool* root_passed = nullptr, float* t_out = nullptr, RayS* final_ray = nullptr) {
-  constexpr bool FASTIN = VOTE;
+  constexpr bool FASTIN = FASTIN_;
   float tmp, tmin = FLT_MAX;
   int hit = -1;
   const NodeRec root = load_node(sc.nodes, 0);
@@ -666,9 +676,9 @@ __device__ int bvh_closest(const DevScene& sc, Stack& st, RayS ray, F3& hit_poin
       if (occluded) desc = kDescHit;\
       else restart_from_bottom();\
   }
-template <bool SPILL, class CT, bool VOTE = SPILL>
+template <int SPILL, class CT, bool VOTE = (SPILL == kStackWindow), bool FASTIN_ = VOTE>
 __device__ bool bvh_any(const DevScene& sc, Stack& st, RayS ray, CT& ct) {
-  constexpr bool FASTIN = VOTE;
+  constexpr bool FASTIN = FASTIN_;
   float tmp;
   const NodeRec root = load_node(sc.nodes, 0);
   ct.add(kNodeTests);
@@ -850,11 +860,11 @@ __device__ bool grid_any(const DevScene& sc, RayS& ray, CT& ct) {
 // ---------------------------------------------------------------------------
 // VOTE: the BVH loops take the kind of step the majority of the wave's lanes needs (bvh_closest); for scenes traversed from
 // global memory, not for LDS-staged ones.
-template <int ACCEL, bool SPILL, bool VOTE, class CT>
+template <int ACCEL, int SPILL, bool VOTE, bool FASTIN = VOTE, class CT>
 __device__ __forceinline__ int closest_hit(const DevScene& sc, Stack& st, RayS& ray, F3& P, Geom& g, CT& ct,
                                            bool* root_passed = nullptr, float* t_out = nullptr) {
   if (ACCEL == P3D_ACCEL_BVH) {
-    const int slot = bvh_closest<SPILL, CT, VOTE>(sc, st, ray, P, g, ct, root_passed, t_out);
+    const int slot = bvh_closest<SPILL, CT, VOTE, FASTIN>(sc, st, ray, P, g, ct, root_passed, t_out);
     return slot < 0 ? -1 : (int)geom_object(g);
   } else if (ACCEL == P3D_ACCEL_GRID) {
     return grid_closest(sc, ray, P, g, ct, t_out);
@@ -867,9 +877,9 @@ __device__ __forceinline__ int closest_hit(const DevScene& sc, Stack& st, RayS& 
   }
 }
 // Shadow feeler (main.cpp:196-217).  Q6: with the grid, brute force runs as well.
-template <int ACCEL, bool SPILL, bool VOTE, class CT>
+template <int ACCEL, int SPILL, bool VOTE, bool FASTIN = VOTE, class CT>
 __device__ __forceinline__ bool any_hit(const DevScene& sc, Stack& st, RayS& feeler, CT& ct) {
-  if (ACCEL == P3D_ACCEL_BVH) return bvh_any<SPILL, CT, VOTE>(sc, st, feeler, ct);
+  if (ACCEL == P3D_ACCEL_BVH) return bvh_any<SPILL, CT, VOTE, FASTIN>(sc, st, feeler, ct);
   bool occluded = false;
   if (ACCEL == P3D_ACCEL_GRID) occluded = grid_any(sc, feeler, ct);
   const bool b = brute_any(sc, feeler, ct);

@@ -758,8 +758,10 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   const uint32_t tp = tph;  // rows per tile band
   P.tile_w_shift = tpw == 8 ? 3 : 2;
   P.tile_h_shift = tph == 8 ? 3 : 2;
-  // (entry size: what the kernel's SPILL parameter says - every kernel over a scene that is not staged, and lds_spill)
-  const size_t lds_bytes = (size_t)P.lds_scene_f4 * sizeof(float4) + (size_t)stack_lds_f4(!lds_scene || lds_spill, cap) * sizeof(float4) +
+  // (entry size: what the kernel's SPILL parameter says - the window for every kernel over a scene that is not staged and for
+  // lds_spill; whole stack in LDS: eight-byte entries for the path tracer, six-byte ones for Whitted)
+  const int stack_mode = (!lds_scene || lds_spill) ? kStackWindow : (pt ? kStackLds8 : kStackLds6);
+  const size_t lds_bytes = (size_t)P.lds_scene_f4 * sizeof(float4) + (size_t)stack_lds_f4(stack_mode, cap) * sizeof(float4) +
                            (sub4 ? sizeof(PtPixelShared) : 0) + (cold_lds ? (size_t)kColdDwords * kBlock * sizeof(float) : 0);
 
   // rows per launch: whole 8-row tile bands, at most kMaxLaunchThreads threads

@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
   DevScene sc = P.sc;
   stage_scene<LDS, true>(sc, P, smem);
 
+  constexpr int PT_STACK = LDS ? kStackLds8 : kStackWindow;  // (device_core.hpp: registers set this kernel's occupancy)
   const uint32_t lane = threadIdx.x;
   constexpr int TP = SUB == 4 ? 4 : 8;                       // tile edge in pixels
   const uint32_t px = SUB == 4 ? lane >> 2 : lane;           // pixel of the tile this lane works for
@@ -89,7 +90,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
   pend.n = 0;
   // after the node stack (only allocated for SUB == 4); explicit LDS address space: a generic
   // pointer would compile to flat_load/flat_store, which are not ordered with the ds_* traffic
-  LdsPtPixelShared& shared = *(LdsPtPixelShared*)(smem + P.lds_scene_f4 + stack_lds_f4(!LDS, P.stack_cap));
+  LdsPtPixelShared& shared = *(LdsPtPixelShared*)(smem + P.lds_scene_f4 + stack_lds_f4(PT_STACK, P.stack_cap));
   if (SUB == 4 && sub == 0) {
     shared.next_start[px] = 0;
     shared.next_add[px] = 0;
@@ -220,7 +221,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
       PT_REGION(2)
       F3 Pn;
       Geom g;
-      const int obj = closest_hit<ACCEL, !LDS, !LDS>(sc, st, ray, Pn, g, ct);
+      const int obj = closest_hit<ACCEL, PT_STACK, !LDS, true>(sc, st, ray, Pn, g, ct);
       PT_REGION(3)
       if (first_ray) {
         first_hit = obj;
@@ -293,7 +294,7 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
           F3 hp2;
           Geom g2;
           PT_REGION(5)
-          const int hit2 = closest_hit<ACCEL, !LDS, !LDS>(sc, st, feeler, hp2, g2, ct);
+          const int hit2 = closest_hit<ACCEL, PT_STACK, !LDS, true>(sc, st, feeler, hp2, g2, ct);
           PT_REGION(6)
           if (hit2 >= 0 && hit2 == (int)lobj) {  // main.cpp:472-475
             const double omega = (double)(2 * kPIf) * (1 - cos_a_max);
