@@ -25,12 +25,6 @@
 // 7 (72) 7.40 / 18.7, 8 (64) 7.37 / 18.7.
 // The work-list launches of the hit_stack hand-off (LIT == 2) are short lists of unrelated deep pixels: every wave waits
 // on its own dependent chain, so what counts is how many waves are resident at once, not registers per wave.
-#ifndef P3D_LITERAL_PASS1_WAVES
-#define P3D_LITERAL_PASS1_WAVES 5  // pass 1 of a LITERAL frame over an LDS-staged scene: held to 96 VGPRs (12 spilled dwords) so that five
-                                   // waves fit a SIMD like the per-pixel kernel's (which needs 96 by itself); on its own it needs
-                                   // 107 = four waves.  cfg2, four frames in flight, same box: 36.8 k -> 39.3 k Mrays/s; a frame alone
-                                   // 0.152 -> 0.157 ms (experiments r03 §13)
-#endif
 #ifndef P3D_LIST_WAVES
 #define P3D_LIST_WAVES 4
 #endif
@@ -456,7 +450,7 @@ __device__ __forceinline__ float4 first_closest_hit(const RenderParams& P, const
 // with the predecessor's leftover, re-trace the first closest hit if the list entry asks for it, and render the unit again
 // if that hit changed.
 template <int ACCEL, bool LDS, bool STATS, bool AA, bool SPILL = !LDS, int SUB = 1, int LIT = 0>
-__global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS && LIT == 1 && !AA) ? P3D_LITERAL_PASS1_WAVES : ((LDS || AA) ? P3D_WHITTED_WAVES : P3D_WHITTED_GLOBAL_WAVES))) whitted_kernel(const RenderParams P) {
+__global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || AA) ? P3D_WHITTED_WAVES : P3D_WHITTED_GLOBAL_WAVES)) whitted_kernel(const RenderParams P) {
   static_assert(SUB == 1 || AA, "four lanes per pixel need more than one sample per pixel");
   static_assert(LIT == 0 || (ACCEL == P3D_ACCEL_BVH && SUB == 1), "only the BVH has a stack to hand on; one lane per pixel");
   extern __shared__ float4 smem[];
