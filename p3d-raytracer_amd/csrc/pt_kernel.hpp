@@ -272,7 +272,6 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
         for (uint32_t k = 0; k < sc.n_emitters; ++k) {  // explicit light sampling, main.cpp:407-477
           const uint32_t lobj = sc.emitters[k];
           const Geom lg = load_geom(sc.ogeom, lobj);
-          const F3 emi = xyz(sc.mats[4 * geom_material(lg) + 3]);
           const F3 center = f3(lg.a.x, lg.a.y, lg.a.z);
           const float rad = lg.a.w;
           const F3 sw = center - intercept_out;
@@ -291,14 +290,18 @@ __global__ void __launch_bounds__(kBlock, P3D_PT_WAVES) pt_kernel(const RenderPa
           RayS feeler;
           ray_set(feeler, intercept_out, l);
           ct.add(kRaysLight);
+          // what main.cpp:472-475 multiplies when the sample is visible, worked out before the traversal: two floats live
+          // through it instead of l, norml and a double (same operands, same operations: same bits)
+          const float omega_f = (float)((double)(2 * kPIf) * (1 - cos_a_max));
+          const float l_dot_n = dot(l, norml);
           F3 hp2;
           Geom g2;
           PT_REGION(5)
           const int hit2 = closest_hit<ACCEL, PT_STACK, !LDS, true>(sc, st, feeler, hp2, g2, ct);
           PT_REGION(6)
           if (hit2 >= 0 && hit2 == (int)lobj) {  // main.cpp:472-475
-            const double omega = (double)(2 * kPIf) * (1 - cos_a_max);
-            e = e + f * (emi * dot(l, norml) * (float)omega) * (1 / kPIf);
+            const F3 emi = xyz(sc.mats[4 * geom_material(load_geom(sc.ogeom, lobj)) + 3]);
+            e = e + f * (emi * l_dot_n * omega_f) * (1 / kPIf);
           }
         }
         L = L + T * (E + e);
