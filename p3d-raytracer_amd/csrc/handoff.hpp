@@ -32,7 +32,7 @@ constexpr uint32_t kHaloChain = 16;       // slots in front of a row that starts
 constexpr uint32_t kMetaTouched = 1u << 17;
 constexpr uint32_t kNoUnit = 0xffffffffu;
 
-enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoPoolTop, kHoListA, kHoListB, kHoListC, kHoListD, kHoNumCounters };
+enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoPoolTop, kHoListA, kHoListB, kHoListC, kHoListD, kHoCheckN, kHoNumCounters };
 constexpr uint32_t kHoErrLeftoverCap = 1u;   // a leftover had more entries than a slot holds, or the leftover pool is full
 constexpr uint32_t kHoErrNoFixedPoint = 2u;  // round bound reached
 constexpr uint32_t kHoErrTrips = 4u;         // sample hand-out loop hit its trip bound (SUB = 4 kernels)
@@ -58,6 +58,11 @@ struct Handoff {
   uint2* entries;
   uint32_t* where;         // compact: [2][n_units] first pool entry of the slot
   uint32_t* pool_top;      // compact: next free pool entry
+  // compact: the units pass 1 left something behind for, in the order their waves finished (one atomic per wave, next to the
+  // pool's).  The check launch runs over THIS list - 64 entries per wave, each checking the unit that starts on the listed
+  // unit's leftover - instead of over every tile with a few lanes to do (100k triangles 2048x2048: 398 k of 4.2 M units).
+  uint32_t* check_list;    // [n_units]; null: the check launch walks the tiles (dense records, per-level launches, LDS-staged scenes)
+  uint32_t* check_n;
   uint32_t pool_cap;       // entries in the pool
   uint32_t dense;
   uint32_t* meta;          // [n_units] bits 0..15 entries of the current slot, bit 16 which slot, bit 17 touched
@@ -140,9 +145,17 @@ __device__ __forceinline__ uint32_t leftover_at(const Handoff& H, uint32_t slot,
 }
 // Room for the n entries a lane wants to leave in `slot` of `unit` (n = 0: none).  EVERY lane of the wave has to call this
 // together (wave prefix sum, one atomic per wave).  Returns the first entry, kNoUnit if the pool is full (status raised).
-__device__ __forceinline__ uint32_t leftover_alloc(const Handoff& H, uint32_t n, uint32_t slot, uint32_t unit, uint32_t* status) {
+// announce (pass 1): the units with n != 0 also go on the check list.
+__device__ __forceinline__ uint32_t leftover_alloc(const Handoff& H, uint32_t n, uint32_t slot, uint32_t unit, uint32_t* status, bool announce) {
   if (H.dense) return (slot * H.n_units + unit) * H.cap;
   const uint32_t lane = threadIdx.x & 63u;
+  if (announce && H.check_list) {
+    const unsigned long long m = __ballot(n != 0);
+    uint32_t first = 0;
+    if (lane == 63 && m) first = atomicAdd(H.check_n, (uint32_t)__popcll(m));
+    first = __shfl(first, 63, 64);
+    if (n != 0) H.check_list[first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = unit;  // (every unit at most once: room for all)
+  }
   uint32_t incl = n;
   for (int o = 1; o < 64; o <<= 1) {
     const uint32_t v = __shfl_up(incl, o, 64);

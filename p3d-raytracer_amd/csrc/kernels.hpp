@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
         }
       }
       if (LIT != 0) {  // every lane: room in the leftover pool (one atomic per wave), then the entries
-        const uint32_t at = leftover_alloc(H, leave_n, leave_slot, unit, P.status);
+        const uint32_t at = leftover_alloc(H, leave_n, leave_slot, unit, P.status, LIT == 1 && !LDS);
         if (at != kNoUnit) {
           for (uint32_t e = 0; e < leave_n; ++e) H.entries[at + e] = stack_read<SPILL>(st, (int)e);
         } else if (leave_n) {  // pool full: the call fails (status); the records must still not point anywhere
@@ -948,6 +948,43 @@ __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParam
     handoff_append(H.list_out, H.n_out, H.list_cap, P.status, make_uint4(unit, (uint32_t)pred, slot_count, 0u));
   else
     replace_ch0_counters<STATS>(H, unit, ct, P.stats);
+}
+
+// The same round over the list pass 1 wrote (Handoff::check_list: the units that left something): entry -> the unit that starts on
+// that leftover (the next one that touched the stack) -> re-trace its first closest hit on it.  Every lane has work; one launch
+// for the whole tile however many launches pass 1 took.
+template <bool LDS, bool SPILL, bool STATS = false>
+__global__ void __launch_bounds__(kBlock) handoff_check_list_kernel(const RenderParams P) {
+  extern __shared__ float4 smem[];
+  const Handoff& H = P.hand;
+  uint32_t n = __hip_atomic_load(H.check_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  n = n > H.n_units ? H.n_units : n;
+  if ((size_t)blockIdx.x * kBlock >= n) return;  // nothing on the list for this workgroup: leave before the scene is staged
+  const uint32_t lane = threadIdx.x;
+  DevScene sc = P.sc;
+  stage_scene<LDS, false>(sc, P, smem);
+  Stack st;
+  stack_bind(st, smem, P.lds_scene_f4, lane, P.stack_cap, P.spill, P.level_stride, blockIdx.x * kBlock + lane);
+  for (uint32_t chunk = blockIdx.x; (size_t)chunk * kBlock < n; chunk += gridDim.x) {
+    const uint32_t i = chunk * kBlock + lane;
+    if (i >= n) continue;
+    const uint32_t pred = H.check_list[i];
+    const uint32_t pm = H.meta[pred];
+    const int succ = handoff_succ(H, pred);
+    if (succ < 0 || (pm & 0xffffu) == 0) continue;  // nobody starts on it (end of a chain) / the pool was full (the call fails)
+    const uint32_t unit = (uint32_t)succ;
+    Counters<STATS> ct;
+    ct.clear();
+    const UnitPlace up = place_of_unit(P, unit);
+    const uint32_t slot_count = pm & 0x1ffffu;
+    seed_stack<SPILL>(st, H, pred, slot_count, ct);
+    if (H.count) atomicAdd(&H.counters[kHoChecked], 1u);
+    const float4 now = first_closest_hit<SPILL, !LDS>(P, sc, st, up.x, up.y, P.antialiasing ? H.first_sample[unit] : 0u, ct);
+    if (!same_first(now, H.first[unit]))
+      handoff_append(H.list_out, H.n_out, H.list_cap, P.status, make_uint4(unit, pred, slot_count, 0u));
+    else
+      replace_ch0_counters<STATS>(H, unit, ct, P.stats);
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -140,7 +140,7 @@ struct p3d_scene {
   float device_bvh_ms = 0;  // GPU time of lbvh::build, 0 for an uploaded tree
   Scratch levels, spill, deferred, wf_rays, wf_keys, wf_sorted, wf_final, out_rgb, out_hit, out_rgb8, q_in, q_out;
   // P3D_STACK_LITERAL (csrc/handoff.hpp): leftovers, per-unit records, work lists, counters
-  Scratch ho_where, ho_entries, ho_meta, ho_first, ho_first_sample, ho_touched, ho_lists, ho_counters, ho_row_chain, ho_halo_pix, ho_ucount;
+  Scratch ho_where, ho_entries, ho_meta, ho_first, ho_first_sample, ho_touched, ho_lists, ho_check, ho_counters, ho_row_chain, ho_halo_pix, ho_ucount;
   std::vector<int64_t> ho_chain_key;     // what the row_chain flags and halo pixels on the device were worked out for
   bool has_spheres = false;              // (halo_find_kernel: only a sphere test re-normalises a ray)
   uint32_t* d_halo_verdict = nullptr;    // kHoErrHalo if the memoised halo search could not start some row exactly
@@ -176,7 +176,7 @@ void p3d_scene_destroy(p3d_scene* s) {
   }
   s->levels.release(); s->spill.release(); s->deferred.release(); s->wf_rays.release(); s->wf_keys.release(); s->wf_sorted.release(); s->wf_final.release(); s->out_rgb.release(); s->out_hit.release();
   s->ho_where.release(); s->ho_entries.release(); s->ho_meta.release(); s->ho_first.release(); s->ho_first_sample.release(); s->ho_touched.release();
-  s->ho_lists.release(); s->ho_counters.release(); s->ho_row_chain.release(); s->ho_halo_pix.release(); s->ho_ucount.release();
+  s->ho_lists.release(); s->ho_check.release(); s->ho_counters.release(); s->ho_row_chain.release(); s->ho_halo_pix.release(); s->ho_ucount.release();
   if (s->d_status) (void)hipFree(s->d_status);
   if (s->d_halo_verdict) (void)hipFree(s->d_halo_verdict);
   s->out_rgb8.release(); s->q_in.release(); s->q_out.release();
@@ -519,7 +519,8 @@ hipError_t launch_accel(bool pt, bool aa, bool sub4, bool lds_scene, bool stats,
   return stats ? launch_one<ACCEL, false, true>(pt, aa, sub4, P, blocks, lds, st) : launch_one<ACCEL, false, false>(pt, aa, sub4, P, blocks, lds, st);
 }
 
-// P3D_STACK_LITERAL launches (BVH only).  lit 1: pass 1; lit 2: work-list launch; lit 0: the check launch.
+// P3D_STACK_LITERAL launches (BVH only).  lit 1: pass 1; lit 2: work-list launch; lit 0: the check launch over the tiles; lit 3:
+// the check launch over pass 1's list.
 template <bool LDS, bool SPILL>
 hipError_t launch_literal_variant(int lit, bool aa, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
   constexpr int A = P3D_ACCEL_BVH;
@@ -533,6 +534,13 @@ hipError_t launch_literal_variant(int lit, bool aa, bool stats, const RenderPara
     else if (aa) hipLaunchKernelGGL((whitted_kernel<A, LDS, false, true, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
     else if (stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, false, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
     else hipLaunchKernelGGL((whitted_kernel<A, LDS, false, false, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
+  } else if (lit == 3) {
+    if constexpr (!LDS) {  // (only scenes traversed from global memory announce: p3d_render_tile_device)
+      if (stats) hipLaunchKernelGGL((handoff_check_list_kernel<LDS, SPILL, true>), dim3(blocks), dim3(kBlock), lds, st, P);
+      else hipLaunchKernelGGL((handoff_check_list_kernel<LDS, SPILL, false>), dim3(blocks), dim3(kBlock), lds, st, P);
+    } else {
+      return hipErrorInvalidValue;
+    }
   } else if (stats) {
     hipLaunchKernelGGL((handoff_check_kernel<LDS, SPILL, true>), dim3(blocks), dim3(kBlock), lds, st, P);
   } else {
@@ -864,6 +872,8 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     touched_bytes = ((size_t)H.n_units / 32 + 2) * 4;
     if (int rc = s->ho_touched.ensure(touched_bytes)) return rc;
     if (int rc = s->ho_lists.ensure((size_t)4 * H.n_units * sizeof(uint4))) return rc;
+    if (!H.dense && !lds_scene)  // the check launch's work list (handoff.hpp Handoff::check_list)
+      if (int rc = s->ho_check.ensure((size_t)H.n_units * sizeof(uint32_t))) return rc;
     // hand-off counters in the first 128-byte line, then one line per (chain level, queue segment) of the per-level launches
     // ... and the bin counts of every level's ray queue
     counter_words = 32 + (per_level ? ((uint32_t)cfg->max_depth + 1) * (kWfSegments * kWfCounterStride + kWfHistWords) : 0);
@@ -902,6 +912,10 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     ho_counters = (uint32_t*)s->ho_counters.p;
     H.counters = ho_counters;
     H.pool_top = ho_counters + kHoPoolTop;
+    // (scenes traversed from global memory only: over an LDS-staged scene 64 unrelated pixels per wave diverge for longer than
+    // the few neighbouring lanes of a tile's wave take, cfg2 literal loop 37.3 k -> 35.1 k Mrays/s; 100k triangles 15.9 -> 15.5 ms)
+    H.check_list = (H.dense || lds_scene) ? nullptr : (uint32_t*)s->ho_check.p;
+    H.check_n = ho_counters + kHoCheckN;
   }
   if (stats && literal) P3D_HIP(hipEventRecord(s->ev0, st));  // kernel_ms of a LITERAL frame is the whole frame: halo search (when not memoised) and clear included
   uint32_t halo_blocks = 0;
@@ -941,6 +955,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   if (stats && literal) P3D_HIP(hipEventRecord(s->ev_p1, st));  // pass1_ms: the speculative pass on its own
   // pass: 0 = the render launches (LITERAL: pass 1, everything on an empty stack); 1 = LITERAL only: the check launches
   for (int pass = 0; pass < (literal ? 2 : 1); ++pass) {
+    if (pass == 1 && H.check_list) break;  // the check runs over pass 1's list, once for the whole tile (below)
     for (uint32_t band0 = 0; band0 < total_bands; band0 += bands_per_launch) {
       const uint32_t nb = std::min(bands_per_launch, total_bands - band0);
       const int row0 = (int)(band0 * tp);
@@ -1043,6 +1058,13 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     // (one workgroup per 64 pixels at most: with few list entries per wave a list of 1 % of the pixels still gets a wave
     // per chunk; workgroups without a chunk leave at once)
     const uint32_t wide = std::max<uint32_t>(1, std::min<uint32_t>(max_threads / kBlock, std::max<uint32_t>(64, H.n_units / kBlock)));
+    if (H.check_list) {  // round 1 of the hand-off over the units pass 1 announced: writes list A
+      H.list_out = ho_list[0]; H.n_out = ho_counters + kHoListA;
+      P.level_stride = wide * kBlock;
+      P.tile_blocks = wide;
+      const hipError_t e = launch_literal(3, cfg->antialiasing != 0, lds_scene, want_counts, P, wide, lds_bytes, st);
+      if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("hand-off check launch: ") + hipGetErrorString(e));
+    }
     for (int round = 0; round < 3; ++round) {
       H.list_in = ho_list[round]; H.n_in = ho_counters + kHoListA + round;
       H.list_out = ho_list[round + 1]; H.n_out = ho_counters + kHoListA + round + 1;
