@@ -491,6 +491,32 @@ def test_leftover_pool_that_runs_full_fails_or_falls_back_to_dense_records():
     assert dev.status() == 0
 
 
+def test_check_over_the_announced_list_equals_the_check_over_the_tiles(tri5k_path):
+    """Round 1 of the hit_stack hand-off has two forms.  Dense records (and every LDS-staged scene): the check launch walks the
+    tiles.  Compact records over a scene traversed from global memory: pass 1 announces the units that left something and the
+    check launch runs over that list (handoff_check_list_kernel).  Same checks, same frame: full frame and a stripe set,
+    both against the oracle's serial order, and the same number of checks and redone units in the statistics."""
+    dev, sc = _pair(tri5k_path, res=(192, 160), grid=False)
+    compact = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=3, collect_stats=1)
+    dense = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=3, collect_stats=1, handoff_records=p3d.HANDOFF_DENSE)
+    o_rgb, o_hit, _ = sc.render(oracle_cfg_like(compact))
+    a, a_hit, a_st = dev.render(compact)
+    b, b_hit, b_st = dev.render(dense)
+    assert_bit_identical((a, a_hit), (o_rgb, o_hit), "check over the list")
+    assert_bit_identical((b, b_hit), (o_rgb, o_hit), "check over the tiles")
+    assert a_st.handoff_checked == b_st.handoff_checked > 0 and a_st.handoff_redone == b_st.handoff_redone
+    for k in ("rays", "node_tests", "tri_tests"):
+        assert getattr(a_st, k) == getattr(b_st, k), k
+    res = (192, 160)
+    for rank in range(2):
+        t = p3d.stripe_tile(res, rank, 2, 8)
+        rows = p3d.stripe_rows(res, rank, 2, 8)
+        for cfg_ in (compact, dense):
+            rgb, hit, _ = dev.render(cfg_, tile=t)
+            assert (rgb.view(np.uint32) == o_rgb[rows].view(np.uint32)).all() and (hit == o_hit[rows]).all()
+    assert dev.status() == 0
+
+
 def test_tile_schedules_of_different_kernel_variants_do_not_mix(tri5k_path):
     """The recorded tile schedule belongs to a tile GRID: the literal anti-aliased launch works on 8x8-pixel tiles, the
     per-pixel one over a scene traversed from L2 on 4x4 tiles with four lanes per pixel.  Rendering one after the other
