@@ -85,13 +85,16 @@ struct SchedEntry {
 };
 constexpr uint32_t kWfHistWords = kWfBins + 32;  // bin counts of one level + the total, padded to a 128-byte multiple
 #ifndef P3D_REDO_LANES
-#define P3D_REDO_LANES 32
+#define P3D_REDO_LANES 64
 #endif
 // List entries per wave of the first work-list launch (the units rendered again: cfg2 9 995 unrelated deep pixels).
-// Measured on cfg2 (profiles/r02/experiments/README.md §7): 4 per wave = 2 500 waves make that launch 130 µs when the
-// frame is alone on the chip, 32 per wave = 313 waves 160 µs (frame 0.338 -> 0.363 ms); but every one of those waves
-// holds a slot and issues for ~100 µs whatever the number of its active lanes, and with other frames in flight that is
-// what counts: four frames in flight 0.21-0.26 -> 0.13-0.16 ms per frame.  P3D_REDO_LANES in the environment overrides it.
+// Fewer entries per wave make that launch shorter when the frame is alone on the chip (round 2, profiles/r02/experiments/
+// README.md §7: 4 per wave 130 µs, 32 per wave 160 µs), but every one of those waves holds a slot and issues for ~100 µs
+// whatever the number of its active lanes, and with other frames in flight that is what counts.  Round 3, final kernels,
+// one box, cfg2 with four frames in flight (1 000-step / 20-step loops) and one frame alone:
+//    8 per wave  24.7 k / 23.8 k Mrays/s, 0.333 ms      32 per wave  36.9 k / 31.6 k, 0.337 ms
+//   16 per wave  32.0 k / 29.5 k,         0.332 ms      64 per wave  38.9 k / 34.0 k, 0.348 ms
+// P3D_REDO_LANES in the environment overrides it.
 inline uint32_t redo_lanes() {
   static const uint32_t v = [] {
     const char* e = getenv("P3D_REDO_LANES");
