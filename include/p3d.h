@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define P3D_ABI_VERSION 3u
+#define P3D_ABI_VERSION 4u /* round 4: p3d_stats.handoff_dense_retry; the test hooks left this header (csrc/p3d_debug.h) */
 
 typedef enum p3d_status {
   P3D_OK = 0,
@@ -306,6 +306,9 @@ typedef struct p3d_stats {
   uint64_t handoff_rounds;   /* rounds until no leftover changed any more */
   double pass1_ms;           /* of kernel_ms: the speculative pass over all pixels (the launches of pass 1 alone) */
   double handoff_ms;         /* of kernel_ms: check, redo and fixed-point launches */
+  uint64_t handoff_dense_retry; /* p3d_render_tile only: 1 = the COMPACT leftover pool was too small for this frame and the
+                                   call rendered it a second time with P3D_HANDOFF_DENSE records (twice the time, and the
+                                   dense records allocated: lights x tree depth entries per pixel) */
 } p3d_stats;
 
 /* Device-resident scene, one per HIP device.  A p3d_scene also owns per-launch scratch and the
@@ -386,18 +389,6 @@ int p3d_render_tile_device(p3d_scene* scene, const p3d_config* cfg, const p3d_ti
  * `stats` ask here: waits for the scene's device, returns P3D_OK or P3D_ERR_CAPACITY and clears the flag.
  */
 int p3d_scene_status(p3d_scene* scene);
-/* Test hook: trip bound of the four-lanes-per-pixel sample loops (0 = the real bound), process-wide. */
-int p3d_debug_set_trip_bound(uint32_t trips);
-/* Test hook: round bound of the hit_stack hand-off (0 = the real bound, min(units + 2, 4096)), process-wide.  A work
- * list that is not empty after that many rounds makes the call fail: the frame would not be the serial one. */
-int p3d_debug_set_max_rounds(uint32_t rounds);
-/* Test hook: how many frame pixels the search in front of a row of a stripe / sub-rectangle may collect before it has to
- * find one whose leftover provably does not depend on its own incoming hit_stack (0 = the real bound, 16), process-wide. */
-int p3d_debug_set_halo_chain(uint32_t pixels);
-/* Test hook: size of the pool of the COMPACT hit_stack leftover records in entries (0 = the real rule: 8 per pixel of the
- * tile, at least 65536), process-wide. */
-int p3d_debug_set_leftover_pool(uint32_t entries);
-
 /*
  * Batched traversal queries — device counterparts of BVH::intersect_bvh
  * (bvh.cpp:198), Grid::Traverse (grid.cpp:71) and the brute-force loop

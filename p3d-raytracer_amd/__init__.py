@@ -33,7 +33,7 @@ HANDOFF_COMPACT, HANDOFF_DENSE = 0, 1
 EXPORTS = [
     "p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_config_default",
     "p3d_scene_create", "p3d_scene_create_device_bvh", "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_render_tile", "p3d_render_tile_device",
-    "p3d_scene_status", "p3d_debug_set_trip_bound", "p3d_debug_set_max_rounds", "p3d_debug_set_halo_chain", "p3d_debug_set_leftover_pool", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
+    "p3d_scene_status", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
     "p3d_trace_closest", "p3d_trace_any", "p3d_host_scene_load", "p3d_host_scene_destroy",
     "p3d_host_scene_set_resolution", "p3d_host_scene_set_lens", "p3d_host_scene_replicate_lights",
     "p3d_host_scene_desc", "p3d_host_scene_bind_device", "p3d_host_scene_has_skybox",
@@ -118,7 +118,8 @@ class Stats(C.Structure):
         "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "rays_bounce", "rays_light",
         "node_tests", "sphere_tests", "tri_tests", "box_tests", "plane_tests", "shaded_hits", "pixels",
         "max_stack")] + [("kernel_ms", C.c_double)] + [(n, C.c_uint64) for n in (
-        "handoff_checked", "handoff_redone", "handoff_rounds")] + [("pass1_ms", C.c_double), ("handoff_ms", C.c_double)]
+        "handoff_checked", "handoff_redone", "handoff_rounds")] + [("pass1_ms", C.c_double), ("handoff_ms", C.c_double),
+                                                                ("handoff_dense_retry", C.c_uint64)]
 
     @property
     def rays(self):
@@ -182,10 +183,7 @@ def lib():
         L.p3d_object_normal.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.p3d_skybox_color.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.p3d_scene_status.argtypes = [C.c_void_p]
-        L.p3d_debug_set_trip_bound.argtypes = [C.c_uint32]
-        L.p3d_debug_set_max_rounds.argtypes = [C.c_uint32]
-        L.p3d_debug_set_halo_chain.argtypes = [C.c_uint32]
-        L.p3d_debug_set_leftover_pool.argtypes = [C.c_uint32]
+        L.p3d_debug_scene_limits.argtypes = [C.c_void_p, C.c_void_p]  # csrc/p3d_debug.h: not part of include/p3d.h
         _lib = L
     return _lib
 
@@ -375,6 +373,12 @@ class DeviceScene:
         """p3d_scene_status: waits for the device, returns P3D_OK (0) or the code of a device-detected error of the
         asynchronous render_device calls since the last check (message: last_error())."""
         return int(self._L.p3d_scene_status(self._h))
+
+    def debug_limits(self, trip_bound=0, max_rounds=0, halo_chain=0, leftover_pool=0):
+        """Tests only (csrc/p3d_debug.h, not part of include/p3d.h): shrink limits of THIS scene so that the device-side
+        error paths fire; all 0 = the real limits.  Refused unless the process was started with P3D_TEST_HOOKS=1."""
+        lim = (C.c_uint32 * 4)(trip_bound, max_rounds, halo_chain, leftover_pool)
+        _check(self._L.p3d_debug_scene_limits(self._h, C.cast(lim, C.c_void_p)))
 
     def render_device(self, cfg, tile, d_rgb=0, d_hit=0, d_rgb8=0, stream=0, stats=None):
         """Device-buffer form: raw HBM addresses (e.g. torch.Tensor.data_ptr()) and a hipStream_t."""

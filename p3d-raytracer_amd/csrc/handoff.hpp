@@ -32,7 +32,7 @@ constexpr uint32_t kHaloChain = 16;       // slots in front of a row that starts
 constexpr uint32_t kMetaTouched = 1u << 17;
 constexpr uint32_t kNoUnit = 0xffffffffu;
 
-enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoPoolTop, kHoListA, kHoListB, kHoListC, kHoListD, kHoCheckN, kHoNumCounters };
+enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoPoolTop, kHoListA, kHoListB, kHoListC, kHoListD, kHoCheckN, kHoRound0, kHoNumCounters };
 constexpr uint32_t kHoErrLeftoverCap = 1u;   // a leftover had more entries than a slot holds, or the leftover pool is full
 constexpr uint32_t kHoErrNoFixedPoint = 2u;  // round bound reached
 constexpr uint32_t kHoErrTrips = 4u;         // sample hand-out loop hit its trip bound (SUB = 4 kernels)
@@ -66,6 +66,7 @@ struct Handoff {
   uint32_t pool_cap;       // entries in the pool
   uint32_t dense;
   uint32_t* meta;          // [n_units] bits 0..15 entries of the current slot, bit 16 which slot, bit 17 touched
+  uint32_t* meta0;         // [n_units] the word as pass 1 wrote it (slot 0), read-only afterwards
   float4* first;           // [n_units] {hit point, object id} of the first closest hit of the first touching sample
   uint32_t* first_sample;  // [n_units] index of that sample (anti-aliased launches)
   uint32_t* touched;       // bit per unit

@@ -31,6 +31,12 @@
 #ifndef P3D_WHITTED_GLOBAL_WAVES
 #define P3D_WHITTED_GLOBAL_WAVES 6
 #endif
+// One-sample-per-pixel instantiations over an LDS-staged scene: 96 VGPRs = five waves per SIMD.  The per-pixel kernel needs
+// exactly that; the literal pass 1 needs 99 without the zero-weight-reflection machinery (GHOSTS = false) and is held to 96
+// without a spilled dword (with it: 107, and holding it to 96 spills 12 dwords - profiles/r03/experiments §13).
+#ifndef P3D_WHITTED_LDS_WAVES
+#define P3D_WHITTED_LDS_WAVES 5
+#endif
 
 namespace p3d {
 
@@ -448,26 +454,61 @@ __device__ __forceinline__ float4 first_closest_hit(const RenderParams& P, const
 // 1 = pass 1: the pixel starts on an empty stack, the samples of the pixel hand the stack on, and the pixel's leftover,
 // its touched flag and its first closest hit are recorded; 2 = the lanes take units from a work list, seed the stack
 // with the predecessor's leftover, re-trace the first closest hit if the list entry asks for it, and render the unit again
-// if that hit changed.
-template <int ACCEL, bool LDS, bool STATS, bool AA, bool SPILL = !LDS, int SUB = 1, int LIT = 0>
-__global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || AA) ? P3D_WHITTED_WAVES : P3D_WHITTED_GLOBAL_WAVES)) whitted_kernel(const RenderParams P) {
+// if that hit changed; 3 = round 1 of the hand-off over the TILES, check and repair in one launch (LDS-staged scenes): every lane
+// whose unit starts on a non-empty leftover re-traces its first closest hit on it (what handoff_check_kernel does) and, if that
+// hit changed, renders the unit again in the same wave (what the first work-list launch did with 64 unrelated pixels per
+// wave: the units to repair of one tile are neighbours and walk the scene together - round 3, one box: the list launch
+// cost the frames-in-flight loop of the bench workload 0.023 of its 0.126 ms per frame, profiles/r04/experiments).
+// GHOSTS: the scene has a material that is transmissive AND reflective, i.e. LITERAL frames trace zero-weight reflection rays
+// (whitted_sample.inc); without one the machinery is compiled out (pass 1 over the bench scene: 107 -> 96 VGPRs, five waves
+// per SIMD like the per-pixel kernel).
+template <int ACCEL, bool LDS, bool STATS, bool AA, bool SPILL = !LDS, int SUB = 1, int LIT = 0, bool GHOSTS = true>
+__global__ void __launch_bounds__(kBlock, LIT >= 2 ? P3D_LIST_WAVES : (AA ? P3D_WHITTED_WAVES : (LDS ? ((LIT == 1 && GHOSTS) ? P3D_WHITTED_WAVES : P3D_WHITTED_LDS_WAVES) : P3D_WHITTED_GLOBAL_WAVES))) whitted_kernel(const RenderParams P) {
   static_assert(SUB == 1 || AA, "four lanes per pixel need more than one sample per pixel");
   static_assert(LIT == 0 || (ACCEL == P3D_ACCEL_BVH && SUB == 1), "only the BVH has a stack to hand on; one lane per pixel");
+  constexpr bool REDO = LIT >= 2;               // launches that render units again, seeded with their predecessor's leftover
+  constexpr bool GHOST = LIT != 0 && GHOSTS;    // zero-weight reflection rays are put aside and traced (whitted_sample.inc)
   extern __shared__ float4 smem[];
   uint32_t tx = 0, ty = 0;
-  const bool halo_block = LIT == 1 && blockIdx.x >= P.tile_blocks;
+  const bool halo_block = (LIT == 1 || LIT == 3) && blockIdx.x >= P.tile_blocks;
   if (LIT != 2 && !halo_block && !tile_of_block(P, tx, ty)) return;
   if (LIT == 2) {  // nothing on the list for this workgroup: leave before the scene is staged
     const uint32_t n0 = __hip_atomic_load(P.hand.n_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if ((size_t)blockIdx.x * P.hand.lanes >= (n0 > P.hand.list_cap ? P.hand.list_cap : n0)) return;
   }
+  const uint32_t lane = threadIdx.x;
+  const uint32_t tws = SUB == 4 ? 2u : P.tile_w_shift, ths = SUB == 4 ? 2u : P.tile_h_shift;  // tile = (1 << tws) x (1 << ths) pixels
+  // LIT == 3: which lanes have anything to re-trace is known before the scene is staged, and most waves leave here.  The
+  // predecessor's record is read from meta0, pass 1's copy: a predecessor repaired by another wave of THIS launch changes
+  // its meta word while this wave may still be reading it (Jacobi: everybody starts from pass 1's leftovers).
+  uint32_t t_unit = 0, t_pred = 0, t_slot_count = 0;
+  bool t_need = false;
+  if (LIT == 3) {
+    const Handoff& H0 = P.hand;
+    bool act;
+    if (halo_block) {
+      act = halo_unit_of_lane(P, lane, t_unit);
+    } else {
+      const int c = (int)((tx << tws) + (lane & ((1u << tws) - 1u))), r = (int)((ty << ths) + (lane >> tws));
+      act = lane < (1u << (tws + ths)) && c < P.w && r < P.h;
+      t_unit = (uint32_t)(P.row0 + r) * H0.row_units + H0.halo + (uint32_t)c;
+    }
+    if (act && handoff_touched(H0, t_unit)) {
+      const int pred = handoff_pred(H0, t_unit);
+      if (pred >= 0) {
+        const uint32_t pm = H0.meta0[pred];
+        t_need = (pm & 0xffffu) != 0;  // otherwise the predecessor left nothing: pass 1's empty stack was right
+        t_pred = (uint32_t)pred;
+        t_slot_count = pm & 0x1ffffu;
+      }
+    }
+    if (__ballot(t_need) == 0) return;
+  }
   P3D_TL_BEGIN()
-  const unsigned long long t_begin = (LIT != 2 && P.tile_cost) ? wall_clock64() : 0;
+  const unsigned long long t_begin = (LIT < 2 && P.tile_cost) ? wall_clock64() : 0;
   DevScene sc = P.sc;
   stage_scene<LDS, ACCEL != P3D_ACCEL_BVH>(sc, P, smem);
 
-  const uint32_t lane = threadIdx.x;
-  const uint32_t tws = SUB == 4 ? 2u : P.tile_w_shift, ths = SUB == 4 ? 2u : P.tile_h_shift;  // tile = (1 << tws) x (1 << ths) pixels
   const uint32_t px = SUB == 4 ? lane >> 2 : lane;  // pixel of the tile this lane works for
   const uint32_t sub = SUB == 4 ? lane & 3u : 0u;
   Counters<STATS> ct;
@@ -525,6 +566,14 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
           up = place_of_unit(P, unit);
           active = up.valid;
         }
+      } else if (LIT == 3) {  // the tile's lanes that start on a non-empty leftover: check first, like a list entry with flag 1
+        active = t_need;
+        unit = t_unit; pred = t_pred; pred_slot_count = t_slot_count; flags = 1u;
+        up.c = up.r = up.x = up.y = 0; up.halo = false; up.valid = false;
+        if (active) {
+          up = place_of_unit(P, unit);
+          active = up.valid;
+        }
       } else if (halo_block) {
         active = halo_unit_of_lane(P, lane, unit);
         up.c = up.r = up.x = up.y = 0; up.halo = true; up.valid = active;
@@ -543,7 +592,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
       bool unit_touched = false;
       uint32_t unit_ch0[kCh0Counters] = {0, 0, 0, 0, 0};
       if (STATS && LIT != 0) ct.clear();  // LITERAL: counters per unit (store_unit_counters), not per lane
-      if (LIT == 2 && active) {  // seed with the predecessor's leftover; re-trace the first closest hit if asked to
+      if (REDO && active) {  // seed with the predecessor's leftover; re-trace the first closest hit if asked to
         seed_stack<SPILL>(st, H, pred, pred_slot_count, ct);
         if (flags & 1u) {
           if (H.count) atomicAdd(&H.counters[kHoChecked], 1u);
@@ -556,7 +605,10 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
           }
           if (STATS) ct.clear();
         }
-        if (active && H.count) atomicAdd(&H.counters[kHoRedone], 1u);
+        if (active && H.count) {
+          atomicAdd(&H.counters[kHoRedone], 1u);
+          if (LIT == 3) atomicOr(&H.counters[kHoRound0], 1u);  // (the tile launch is a round of its own if it repaired anything)
+        }
       }
       if (LIT == 1) stack_clear(st);
       uint32_t leave_n = 0, leave_slot = 0;  // LIT != 0: entries this lane's unit leaves, stored after the lanes have come together again
@@ -665,6 +717,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
           }
         }
 
+#ifndef P3D_ABL_NO_RECORDS  // (timing ablation only: pass 1 keeps no records, the frame is the per-pixel one)
         if (LIT == 1) {  // what this unit leaves behind (slot 0), whether it touched the stack, its first closest hit
           uint32_t meta = 0;
           if (unit_touched) {
@@ -675,12 +728,14 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
             atomicOr(&H.touched[unit >> 5], 1u << (unit & 31u));
           }
           H.meta[unit] = meta;
+          H.meta0[unit] = meta;  // pass 1's record, never changed by a repair (what the tile launch of round 1 reads of its predecessors)
         }
+#endif
         if (LIT != 0 && STATS) {
           if (up.halo) ct.clear();  // a halo pixel is rendered for its leftover, it is not a pixel of this tile
           store_unit_counters<STATS>(H, unit, ct, unit_ch0, P.stats);
         }
-        if (LIT == 2) {  // a changed leftover goes to the unit's other slot and sends the successor to the next round
+        if (REDO) {  // a changed leftover goes to the unit's other slot and sends the successor to the next round
           const uint32_t meta = H.meta[unit];
           const uint32_t cur = (meta >> 16) & 1u, cnt = meta & 0xffffu;
           uint32_t n = (uint32_t)st.sp;
@@ -699,7 +754,11 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
           }
         }
       }
+#ifdef P3D_ABL_NO_RECORDS
+      if (REDO) {
+#else
       if (LIT != 0) {  // every lane: room in the leftover pool (one atomic per wave), then the entries
+#endif
         const uint32_t at = leftover_alloc(H, leave_n, leave_slot, unit, P.status, LIT == 1 && !LDS);
         if (at != kNoUnit) {
           for (uint32_t e = 0; e < leave_n; ++e) H.entries[at + e] = stack_read<SPILL>(st, (int)e);
@@ -707,7 +766,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
           leave_n = 0;
           H.meta[unit] = (leave_slot << 16) | kMetaTouched;
         }
-        if (LIT == 2 && leave_succ) {
+        if (REDO && leave_succ) {
           const int succ = handoff_succ(H, unit);
           if (succ >= 0) handoff_append(list_out, n_out_p, H.list_cap, P.status, make_uint4((uint32_t)succ, unit, (leave_slot << 16) | leave_n, 1u));
         }
@@ -723,7 +782,7 @@ __global__ void __launch_bounds__(kBlock, LIT == 2 ? P3D_LIST_WAVES : ((LDS || A
     uint32_t* tn = n_in_p; n_in_p = n_out_p; n_out_p = tn;
   }
   if (STATS && LIT == 0) flush_stats<STATS>(ct, P.stats);  // LITERAL: ucount_reduce_kernel
-  if (LIT != 2 && !halo_block) record_tile_cost(P, tx, ty, t_begin);
+  if (LIT < 2 && !halo_block) record_tile_cost(P, tx, ty, t_begin);
   P3D_TL_END()
 }
 

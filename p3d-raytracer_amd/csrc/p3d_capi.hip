@@ -15,6 +15,7 @@
 #include "kernels.hpp"
 #include "lbvh.hpp"
 #include "p3d.h"
+#include "p3d_debug.h"
 #include "pt_kernel.hpp"
 
 using namespace p3d;
@@ -103,11 +104,15 @@ inline uint32_t redo_lanes() {
   }();
   return v;
 }
-uint32_t g_debug_trip_bound = 0;  // tests: force the sample hand-out loops of the SUB = 4 kernels to give up early
-uint32_t g_debug_max_rounds = 0;  // tests: round bound of the hit_stack hand-off (0 = the real one)
-uint32_t g_debug_halo_chain = 0;  // tests: pixels halo_find_kernel may collect in front of a row (0 = kHaloChain)
+#ifdef P3D_ABLATION  // timing experiments only (profiles/r04/experiments): stages of the literal frame left out, frames WRONG
+inline uint32_t abl_skip() {  // P3D_ABL_SKIP: 1 = no check launch, 2 = no redo launch (round 0), 4 = no round 1 / persistent launch
+  static const uint32_t v = [] { const char* e = getenv("P3D_ABL_SKIP"); return e ? (uint32_t)atoi(e) : 0u; }();
+  return v;
+}
+#else
+constexpr uint32_t abl_skip() { return 0; }
+#endif
 constexpr uint32_t kPoolEntriesPerUnit = 8;  // compact hand-off records: pool entries per unit of the tile
-uint32_t g_debug_pool_entries = 0;           // tests: the whole pool (0 = the real rule)
 
 // Tile of a wave of the one-lane-per-pixel Whitted kernels over a scene traversed from L2 (see p3d_render_tile_device).
 // P3D_TILE_SHAPE = 88 | 84 | 44 in the environment overrides the rule (experiments).
@@ -151,6 +156,8 @@ struct p3d_scene {
   bool zero_weight_reflections = false;  // some material is transmissive AND reflective (main.cpp:282,290-300)
   unsigned long long* d_stats = nullptr;
   uint32_t* d_status = nullptr;          // kHoErr* bits raised by kernels; read and cleared by check_status()
+  uint32_t last_status = 0;              // the bits check_status() found last (what the host-buffer call decides its DENSE retry on)
+  p3d_debug_limits dbg{0, 0, 0, 0};      // tests only (csrc/p3d_debug.h): shrunken limits of THIS scene, all 0 = the real ones
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr, ev_p1 = nullptr;
 };
 
@@ -212,6 +219,7 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
   if (d->n_bvh_nodes) {  // every index a lane may follow is checked here, not in the kernel
     if (!d->bvh_nodes || (d->n_bvh_prim_index && !d->bvh_prim_index) || d->n_bvh_prim_index != d->n_prims)
       return fail(P3D_ERR_INVALID, "p3d_scene_create: inconsistent BVH arrays");
+    std::vector<uint8_t> has_parent(d->n_bvh_nodes, 0);  // a TREE: every record is the child of at most one inner node
     for (uint32_t i = 0; i < d->n_bvh_nodes; ++i) {
       const p3d_bvh_node& n = d->bvh_nodes[i];
       if (n.index > 0x0fffffffu) return fail(P3D_ERR_CAPACITY, "p3d_scene_create: BVH index exceeds 2^28");
@@ -221,6 +229,11 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
         if ((uint64_t)n.index + cnt > d->n_bvh_prim_index) return fail(P3D_ERR_INVALID, "p3d_scene_create: BVH leaf range out of bounds");
       } else if ((uint64_t)n.index + 1 >= d->n_bvh_nodes || n.index <= i) {
         return fail(P3D_ERR_INVALID, "p3d_scene_create: BVH child index out of bounds");
+      } else {
+        // (children lie behind their parent, so index 0 is nobody's child; a record with two parents - shared or
+        // overlapping child pairs - would make the relabelling walk below, and every traversal, visit a DAG)
+        if (has_parent[n.index] || has_parent[n.index + 1]) return fail(P3D_ERR_INVALID, "p3d_scene_create: BVH record with more than one parent (not a tree)");
+        has_parent[n.index] = has_parent[n.index + 1] = 1;
       }
     }
     for (uint32_t i = 0; i < d->n_bvh_prim_index; ++i)
@@ -308,7 +321,8 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
       float descf;
       std::memcpy(&descf, &desc, 4);
       blob[s->off_nodes + 2 * (size_t)at] = make_float4(n.bmin[0], n.bmin[1], n.bmin[2], descf);
-      blob[s->off_nodes + 2 * (size_t)at + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], 0.f);      for (int k = 0; k < 3; ++k)  // the slab fast paths assume finite boxes with min <= max (device_core.hpp)
+      blob[s->off_nodes + 2 * (size_t)at + 1] = make_float4(n.bmax[0], n.bmax[1], n.bmax[2], 0.f);
+      for (int k = 0; k < 3; ++k)  // the slab fast paths assume finite boxes with min <= max (device_core.hpp); only uploaded records matter
         if (!(std::fabs(n.bmin[k]) < INFINITY) || !(std::fabs(n.bmax[k]) < INFINITY) || !(n.bmin[k] <= n.bmax[k])) odd_boxes = true;
     };
     put(0, 0);
@@ -523,21 +537,29 @@ hipError_t launch_accel(bool pt, bool aa, bool sub4, bool lds_scene, bool stats,
 }
 
 // P3D_STACK_LITERAL launches (BVH only).  lit 1: pass 1; lit 2: work-list launch; lit 0: the check launch over the tiles; lit 3:
-// the check launch over pass 1's list.
-template <bool LDS, bool SPILL>
-hipError_t launch_literal_variant(int lit, bool aa, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+// the check launch over pass 1's list; lit 4: check + repair over the tiles in one launch (whitted_kernel LIT = 3).
+// ghosts: the scene has zero-weight reflection rays to trace (a transmissive AND reflective material).
+template <bool LDS, bool SPILL, int LIT, bool GHOSTS>
+hipError_t launch_whitted_literal(bool aa, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
   constexpr int A = P3D_ACCEL_BVH;
-  if (lit == 1) {
-    if (aa && stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, true, SPILL, 1, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
-    else if (aa) hipLaunchKernelGGL((whitted_kernel<A, LDS, false, true, SPILL, 1, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
-    else if (stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, false, SPILL, 1, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
-    else hipLaunchKernelGGL((whitted_kernel<A, LDS, false, false, SPILL, 1, 1>), dim3(blocks), dim3(kBlock), lds, st, P);
-  } else if (lit == 2) {
-    if (aa && stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, true, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
-    else if (aa) hipLaunchKernelGGL((whitted_kernel<A, LDS, false, true, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
-    else if (stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, false, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
-    else hipLaunchKernelGGL((whitted_kernel<A, LDS, false, false, SPILL, 1, 2>), dim3(blocks), dim3(kBlock), lds, st, P);
-  } else if (lit == 3) {
+  if (aa && stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, true, SPILL, 1, LIT, GHOSTS>), dim3(blocks), dim3(kBlock), lds, st, P);
+  else if (aa) hipLaunchKernelGGL((whitted_kernel<A, LDS, false, true, SPILL, 1, LIT, GHOSTS>), dim3(blocks), dim3(kBlock), lds, st, P);
+  else if (stats) hipLaunchKernelGGL((whitted_kernel<A, LDS, true, false, SPILL, 1, LIT, GHOSTS>), dim3(blocks), dim3(kBlock), lds, st, P);
+  else hipLaunchKernelGGL((whitted_kernel<A, LDS, false, false, SPILL, 1, LIT, GHOSTS>), dim3(blocks), dim3(kBlock), lds, st, P);
+  return hipGetLastError();
+}
+template <bool LDS, bool SPILL>
+hipError_t launch_literal_variant(int lit, bool ghosts, bool aa, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+  if (lit == 1) return ghosts ? launch_whitted_literal<LDS, SPILL, 1, true>(aa, stats, P, blocks, lds, st) : launch_whitted_literal<LDS, SPILL, 1, false>(aa, stats, P, blocks, lds, st);
+  if (lit == 2) return ghosts ? launch_whitted_literal<LDS, SPILL, 2, true>(aa, stats, P, blocks, lds, st) : launch_whitted_literal<LDS, SPILL, 2, false>(aa, stats, P, blocks, lds, st);
+  if (lit == 4) {
+    if constexpr (LDS) {  // (only LDS-staged scenes repair over the tiles: p3d_render_tile_device)
+      return ghosts ? launch_whitted_literal<LDS, SPILL, 3, true>(aa, stats, P, blocks, lds, st) : launch_whitted_literal<LDS, SPILL, 3, false>(aa, stats, P, blocks, lds, st);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  if (lit == 3) {
     if constexpr (!LDS) {  // (only scenes traversed from global memory announce: p3d_render_tile_device)
       if (stats) hipLaunchKernelGGL((handoff_check_list_kernel<LDS, SPILL, true>), dim3(blocks), dim3(kBlock), lds, st, P);
       else hipLaunchKernelGGL((handoff_check_list_kernel<LDS, SPILL, false>), dim3(blocks), dim3(kBlock), lds, st, P);
@@ -552,10 +574,10 @@ hipError_t launch_literal_variant(int lit, bool aa, bool stats, const RenderPara
   return hipGetLastError();
 }
 // lit 0 here = the check kernel
-hipError_t launch_literal(int lit, bool aa, bool lds_scene, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
-  if (lds_scene && P.stack_spills) return launch_literal_variant<true, true>(lit, aa, stats, P, blocks, lds, st);
-  if (lds_scene) return launch_literal_variant<true, false>(lit, aa, stats, P, blocks, lds, st);
-  return launch_literal_variant<false, true>(lit, aa, stats, P, blocks, lds, st);
+hipError_t launch_literal(int lit, bool ghosts, bool aa, bool lds_scene, bool stats, const RenderParams& P, uint32_t blocks, size_t lds, hipStream_t st) {
+  if (lds_scene && P.stack_spills) return launch_literal_variant<true, true>(lit, ghosts, aa, stats, P, blocks, lds, st);
+  if (lds_scene) return launch_literal_variant<true, false>(lit, ghosts, aa, stats, P, blocks, lds, st);
+  return launch_literal_variant<false, true>(lit, ghosts, aa, stats, P, blocks, lds, st);
 }
 
 // Looks up the schedule for the launch described by (cfg, P).  Known key: P.sched is set.  New
@@ -628,6 +650,7 @@ uint32_t stack_bound(const p3d_scene* s, uint32_t accel, bool whitted) {
 int check_status(p3d_scene* s) {
   uint32_t h = 0;
   P3D_HIP(hipMemcpy(&h, s->d_status, sizeof(h), hipMemcpyDeviceToHost));
+  s->last_status = h;
   if (!h) return P3D_OK;
   P3D_HIP(hipMemset(s->d_status, 0, sizeof(uint32_t)));
   std::string what;
@@ -664,7 +687,7 @@ int finish_stats(p3d_scene* s, hipStream_t st, p3d_stats* stats, bool literal) {
   if (literal) {
     uint32_t c[kHoNumCounters];
     P3D_HIP(hipMemcpy(c, s->ho_counters.p, sizeof(c), hipMemcpyDeviceToHost));
-    stats->handoff_checked = c[kHoChecked]; stats->handoff_redone = c[kHoRedone]; stats->handoff_rounds = c[kHoRounds];
+    stats->handoff_checked = c[kHoChecked]; stats->handoff_redone = c[kHoRedone]; stats->handoff_rounds = c[kHoRounds] + (c[kHoRound0] ? 1 : 0);
   }
   return check_status(s);
 }
@@ -701,6 +724,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   if (cfg->skybox && !s->has_sky) return fail(P3D_ERR_INVALID, "config asks for SKYBOX but no cubemap was supplied (p3d_scene_set_skybox)");
   P3D_HIP(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)hip_stream;
+  s->last_status = 0;
 
   // main.cpp:804-812: without ANTIALIASING the frame loop always calls rayTracing
   const bool pt = cfg->integrator == P3D_PATHTRACE && cfg->antialiasing;
@@ -724,7 +748,9 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   const bool lds_spill = lds_scene && !pt && (bound > 24 || stage_bytes + (size_t)stack_lds_f4(false, bound) * sizeof(float4) > 20 * 1024);
   // Spilling stack (scenes traversed from L2; LDS-staged scenes whose worst case does not fit): LDS holds a window of the
   // most recent `window` entries (a power of two, device_core.hpp "Stack"), older entries sink into a per-thread column of
-  // a global backing array.  8 entries = 4 KB per wave: all 32 wave slots of a CU fit its 160 KB of LDS.
+  // a global backing array.  8 entries = 4 KB per wave; the Whitted kernels that trade registers for waves keep 2.3 KB of
+  // cold shading state behind it (cold_lds below): 6.4 KB per wave = 25 waves per CU by LDS, one more than the 24 (6 per
+  // SIMD) those kernels' registers allow.
   uint32_t window = 8;
   if (const char* e = getenv("P3D_LDS_STACK_ENTRIES")) {  // experiments: LDS entries per lane (rounded up to a power of two)
     window = 1;
@@ -748,7 +774,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   P.stripe_h = tile->stripe_h > 0 ? tile->stripe_h : 0; P.stripe_stride = ss;
   P.stats = s->d_stats;
   P.status = s->d_status;
-  P.debug_trip_bound = g_debug_trip_bound;
+  P.debug_trip_bound = s->dbg.trip_bound;
   P.stack_cap = (int32_t)cap;
   P.stack_spills = lds_spill ? 1u : 0u;
   P.lds_scene_f4 = P.blob_f4;
@@ -862,14 +888,14 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     // leftover records: a pool with 8 entries per unit on average and an offset table (compact), or the worst case of
     // every unit (dense: the per-level launches rewrite a unit's record level by level; p3d_config.handoff_records)
     H.dense = (per_level || cfg->handoff_records == P3D_HANDOFF_DENSE) ? 1u : 0u;
-    uint64_t pool_entries = H.dense ? (uint64_t)2 * H.cap * H.n_units : g_debug_pool_entries ? g_debug_pool_entries : std::max<uint64_t>(1u << 16, (uint64_t)kPoolEntriesPerUnit * H.n_units);
+    uint64_t pool_entries = H.dense ? (uint64_t)2 * H.cap * H.n_units : s->dbg.leftover_pool ? s->dbg.leftover_pool : std::max<uint64_t>(1u << 16, (uint64_t)kPoolEntriesPerUnit * H.n_units);
     if (!H.dense) pool_entries = std::min<uint64_t>(pool_entries, (uint64_t)2 * H.cap * H.n_units);  // never more than dense would take
     if (pool_entries > 0xffffffffull) return fail(P3D_ERR_CAPACITY, "hit_stack hand-off records exceed 2^32 entries: render the frame in smaller tiles or use P3D_STACK_PER_PIXEL");
     H.pool_cap = (uint32_t)pool_entries;
     if (int rc = s->ho_entries.ensure((size_t)pool_entries * sizeof(uint2))) return rc;
     if (!H.dense)
       if (int rc = s->ho_where.ensure((size_t)2 * H.n_units * sizeof(uint32_t))) return rc;
-    if (int rc = s->ho_meta.ensure((size_t)H.n_units * 4)) return rc;
+    if (int rc = s->ho_meta.ensure((size_t)2 * H.n_units * 4)) return rc;  // meta | meta0 (pass 1's copy)
     if (int rc = s->ho_first.ensure((size_t)H.n_units * sizeof(float4))) return rc;
     if (int rc = s->ho_first_sample.ensure(cfg->antialiasing ? (size_t)H.n_units * 4 : 16)) return rc;
     touched_bytes = ((size_t)H.n_units / 32 + 2) * 4;
@@ -891,6 +917,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     H.entries = (uint2*)s->ho_entries.p;
     H.where = (uint32_t*)s->ho_where.p;
     H.meta = (uint32_t*)s->ho_meta.p;
+    H.meta0 = H.meta + H.n_units;
     H.first = (float4*)s->ho_first.p;
     H.first_sample = (uint32_t*)s->ho_first_sample.p;
     H.touched = (uint32_t*)s->ho_touched.p;
@@ -910,7 +937,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     H.list_cap = H.n_units;
     H.count = want_counts ? 1u : 0u;
     H.max_rounds = std::min<uint32_t>(H.n_units + 2, 4096);  // a chain of n units is exact after n rounds at the latest; measured: 2.  Beyond the cap: P3D_ERR_CAPACITY
-    if (g_debug_max_rounds) H.max_rounds = g_debug_max_rounds;
+    if (s->dbg.max_rounds) H.max_rounds = s->dbg.max_rounds;
     for (int i = 0; i < 4; ++i) ho_list[i] = (uint4*)s->ho_lists.p + (size_t)i * H.n_units;
     ho_counters = (uint32_t*)s->ho_counters.p;
     H.counters = ho_counters;
@@ -927,7 +954,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     // The chain flags and the pixels in front of every chain row are a function of the tile and of what shapes the
     // primary rays (the scene and its camera are fixed): worked out by two launches on this stream when any of that
     // changes, kept otherwise (the frames of a sequence find them ready).
-    const uint32_t max_chain = g_debug_halo_chain ? std::min<uint32_t>(g_debug_halo_chain, kHaloChain) : kHaloChain;
+    const uint32_t max_chain = s->dbg.halo_chain ? std::min<uint32_t>(s->dbg.halo_chain, kHaloChain) : kHaloChain;
     const std::vector<int64_t> key = {tile->x0, tile->y0, tile->w, tile->h, tile->stripe_h, tile->stripe_stride, cam.res_x, cam.res_y,
                                       cfg->antialiasing ? 1 : 0, cfg->antialiasing ? (int64_t)cfg->spp_sqrt : 1, (int64_t)cfg->seed,
                                       cfg->sample_mode, cfg->depth_of_field, cfg->sample_disk, max_chain, (int64_t)(intptr_t)st};
@@ -956,8 +983,14 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     if (stats && !literal) P3D_HIP(hipEventRecord(s->ev0, st));
   }
   if (stats && literal) P3D_HIP(hipEventRecord(s->ev_p1, st));  // pass1_ms: the speculative pass on its own
+  // Round 1 of the hand-off over an LDS-staged scene: check AND repair over the tiles in one launch (whitted_kernel LIT = 3)
+  // instead of a check launch that fills a list and a launch that renders the listed units again, 64 unrelated pixels per wave.
+  const bool repair_tiles = literal && lds_scene && !per_level;
+  const bool ghosts = s->zero_weight_reflections;
+  std::vector<const uint32_t*> band_sched;  // the tile schedule pass 1 used for each band: the tile launch of round 1 takes the same order
   // pass: 0 = the render launches (LITERAL: pass 1, everything on an empty stack); 1 = LITERAL only: the check launches
   for (int pass = 0; pass < (literal ? 2 : 1); ++pass) {
+    if (pass == 1 && (abl_skip() & 1u)) break;
     if (pass == 1 && H.check_list) break;  // the check runs over pass 1's list, once for the whole tile (below)
     for (uint32_t band0 = 0; band0 < total_bands; band0 += bands_per_launch) {
       const uint32_t nb = std::min(bands_per_launch, total_bands - band0);
@@ -981,6 +1014,8 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       SchedEntry* fresh = nullptr;
       if (pass == 0 && sched_ok && tiles_x * nb >= (lds_scene ? kSchedMinTiles : kSchedMinTilesL2))
         if (int rc = schedule_lookup(s, cfg, pt, P, st, &fresh)) return rc;
+      if (pass == 0) band_sched.push_back(fresh ? (const uint32_t*)fresh->sched.p : P.sched);
+      if (pass == 1 && repair_tiles) P.sched = band_sched[band0 / bands_per_launch];  // (built on this stream by now: schedule_finish)
       const uint32_t tile_blocks = blocks_for(tiles_x * nb);
       const uint32_t blocks = tile_blocks + (band0 == 0 ? halo_blocks : 0);  // the halo chains ride on the first launch
       P.tile_blocks = tile_blocks;
@@ -1031,8 +1066,8 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
         }
         P.level_stride = blocks * kBlock;
       } else if (literal) {
-        if (pass == 1) { H.list_out = ho_list[0]; H.n_out = ho_counters + kHoListA; }
-        e = launch_literal(pass == 0 ? 1 : 0, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
+        if (pass == 1) { H.list_out = ho_list[repair_tiles ? 1 : 0]; H.n_out = ho_counters + kHoListA + (repair_tiles ? 1 : 0); }
+        e = launch_literal(pass == 0 ? 1 : (repair_tiles ? 4 : 0), ghosts, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
       } else {
         switch (cfg->accel) {
           case P3D_ACCEL_BVH: e = launch_accel<P3D_ACCEL_BVH>(pt, cfg->antialiasing != 0, sub4, lds_scene, want_counts, P, blocks, lds_bytes, st); break;
@@ -1061,14 +1096,16 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     // (one workgroup per 64 pixels at most: with few list entries per wave a list of 1 % of the pixels still gets a wave
     // per chunk; workgroups without a chunk leave at once)
     const uint32_t wide = std::max<uint32_t>(1, std::min<uint32_t>(max_threads / kBlock, std::max<uint32_t>(64, H.n_units / kBlock)));
-    if (H.check_list) {  // round 1 of the hand-off over the units pass 1 announced: writes list A
+    if (H.check_list && !(abl_skip() & 1u)) {  // round 1 of the hand-off over the units pass 1 announced: writes list A
       H.list_out = ho_list[0]; H.n_out = ho_counters + kHoListA;
       P.level_stride = wide * kBlock;
       P.tile_blocks = wide;
-      const hipError_t e = launch_literal(3, cfg->antialiasing != 0, lds_scene, want_counts, P, wide, lds_bytes, st);
+      const hipError_t e = launch_literal(3, ghosts, cfg->antialiasing != 0, lds_scene, want_counts, P, wide, lds_bytes, st);
       if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("hand-off check launch: ") + hipGetErrorString(e));
     }
     for (int round = 0; round < 3; ++round) {
+      if ((round == 0 && (abl_skip() & 2u)) || (round > 0 && (abl_skip() & 4u))) continue;
+      if (round == 0 && repair_tiles) continue;  // the tile launch above was round 0 and wrote list B
       H.list_in = ho_list[round]; H.n_in = ho_counters + kHoListA + round;
       H.list_out = ho_list[round + 1]; H.n_out = ho_counters + kHoListA + round + 1;
       H.persistent = round == 2 ? 1u : 0u;
@@ -1078,7 +1115,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       const uint32_t blocks = round == 2 ? 1u : wide;
       P.level_stride = blocks * kBlock;
       P.tile_blocks = blocks;
-      const hipError_t e = launch_literal(2, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
+      const hipError_t e = launch_literal(2, ghosts, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
       if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("hand-off kernel launch: ") + hipGetErrorString(e));
     }
     if (want_counts) {
@@ -1097,20 +1134,12 @@ int p3d_scene_status(p3d_scene* s) {
   return check_status(s);
 }
 
-int p3d_debug_set_trip_bound(uint32_t trips) {
-  g_debug_trip_bound = trips;
-  return P3D_OK;
-}
-int p3d_debug_set_max_rounds(uint32_t rounds) {
-  g_debug_max_rounds = rounds;
-  return P3D_OK;
-}
-int p3d_debug_set_halo_chain(uint32_t pixels) {
-  g_debug_halo_chain = pixels;
-  return P3D_OK;
-}
-int p3d_debug_set_leftover_pool(uint32_t entries) {
-  g_debug_pool_entries = entries;
+// csrc/p3d_debug.h (not part of include/p3d.h): refused unless the process was started with P3D_TEST_HOOKS=1
+int p3d_debug_scene_limits(p3d_scene* s, const p3d_debug_limits* limits) {
+  static const bool enabled = [] { const char* e = getenv("P3D_TEST_HOOKS"); return e && e[0] == '1' && e[1] == 0; }();
+  if (!enabled) return fail(P3D_ERR_UNSUPPORTED, "p3d_debug_scene_limits: test hooks are off (start the process with P3D_TEST_HOOKS=1)");
+  if (!s) return fail(P3D_ERR_INVALID, "p3d_debug_scene_limits: null scene");
+  s->dbg = limits ? *limits : p3d_debug_limits{0, 0, 0, 0};
   return P3D_OK;
 }
 
@@ -1126,12 +1155,15 @@ int p3d_render_tile(p3d_scene* s, const p3d_config* cfg, const p3d_tile* tile, f
   p3d_stats local;
   int rc = p3d_render_tile_device(s, cfg, tile, rgb ? (float*)s->out_rgb.p : nullptr, hit_id ? (int32_t*)s->out_hit.p : nullptr,
                                   rgb8 ? (uint8_t*)s->out_rgb8.p : nullptr, nullptr, stats ? stats : &local);
-  if (rc == P3D_ERR_CAPACITY && cfg->handoff_records == P3D_HANDOFF_COMPACT && std::strstr(p3d_last_error(), "handoff_records")) {
+  bool retried = false;
+  if (rc == P3D_ERR_CAPACITY && cfg->handoff_records == P3D_HANDOFF_COMPACT && (s->last_status & kHoErrLeftoverCap)) {
     p3d_config dense = *cfg;  // the leftover pool was too small for this frame: once more with room for the worst case
     dense.handoff_records = P3D_HANDOFF_DENSE;
     rc = p3d_render_tile_device(s, &dense, tile, rgb ? (float*)s->out_rgb.p : nullptr, hit_id ? (int32_t*)s->out_hit.p : nullptr,
                                 rgb8 ? (uint8_t*)s->out_rgb8.p : nullptr, nullptr, stats ? stats : &local);
+    retried = true;
   }
+  if (stats && rc == P3D_OK) stats->handoff_dense_retry = retried ? 1 : 0;  // the frame was rendered twice (and the dense records allocated)
   if (rc) return rc;
   if (rgb) P3D_HIP(hipMemcpy(rgb, s->out_rgb.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
   if (hit_id) P3D_HIP(hipMemcpy(hit_id, s->out_hit.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));

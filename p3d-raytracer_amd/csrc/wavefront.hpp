@@ -124,6 +124,7 @@ __global__ void __launch_bounds__(kBlock, P3D_WF_WAVES) wf_level_kernel(const Re
       const int si = 0, sj = 0, SPP = 1;
       int depth = P.max_depth - (int)level;
       const bool ghost = false;
+      constexpr bool GHOST = false;  // (the per-level launches are not used for scenes with zero-weight reflection rays)
       int n_deferred = 0, first_hit = -1;
       Rng rng;
       rng.state = 0; rng.inc = 1;

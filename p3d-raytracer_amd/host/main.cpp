@@ -17,6 +17,10 @@
 //                               one process driving them), every GPU's part of the image brought to GPU 0 by ONE
 //                               ncclGather over xGMI (RCCL, loaded at run time), de-interleaved on the host.  Same image
 //                               as one GPU renders, bit for bit (P3D_STACK_LITERAL included: include/p3d.h, p3d_tile).
+//              [--verify]       with --gpus: one more frame whose float RGB + hit IDs (16 B/px, what bench.py gathers) go
+//                               through a second ncclGather; GPU 0 then renders the whole frame alone and the gathered
+//                               frame is compared with it bit for bit - colours, hit IDs and the u8 image.  Prints the
+//                               verdict; a mismatch is exit code 3.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -134,7 +138,7 @@ constexpr int kNcclUint8 = 1;  // rccl.h: ncclUint8
 constexpr int kStripeRows = 8;
 
 // Renders the frame on n GPUs into `img` (bottom row first, 3 bytes per pixel).  Returns 0, or 1 after printing why not.
-int render_multi_gpu(const p3d_scene_desc* desc, bool device_bvh, p3d_config cfg, int n, std::vector<uint8_t>& img, double* secs) {
+int render_multi_gpu(const p3d_scene_desc* desc, bool device_bvh, p3d_config cfg, int n, bool verify, std::vector<uint8_t>& img, double* secs) {
   const int W = desc->camera.res_x, H = desc->camera.res_y;
   int ndev = p3d_device_count();
   if (n > ndev) { std::fprintf(stderr, "--gpus %d: this node shows %d HIP device(s)\n", n, ndev); return 1; }
@@ -189,6 +193,66 @@ int render_multi_gpu(const p3d_scene_desc* desc, bool device_bvh, p3d_config cfg
       const int y = ((r / kStripeRows) * n + d) * kStripeRows + r % kStripeRows;
       std::memcpy(&img[(size_t)y * row_bytes], &all[(size_t)d * part + (size_t)r * row_bytes], row_bytes);
     }
+  int verdict = 0;
+  if (verify) {
+    // One more frame, all outputs: every GPU renders float RGB + hit IDs (packed: 12 B/px of colour, then 4 B/px of IDs,
+    // for its own rows) next to the u8 image; the packed buffers go to GPU 0 through a second gather.  Then GPU 0 renders
+    // the whole frame alone and the de-interleaved gathered frame must equal it bit for bit (SURVEY.md 8(e) invariant).
+    const size_t px_part = (size_t)W * (H / n), packed = px_part * 16;
+    std::vector<uint8_t*> d_packed(n, nullptr);
+    uint8_t* d_packed_all = nullptr;
+    bool ok = true;
+    for (int d = 0; d < n && ok; ++d) {
+      ok = hip_ok(hipSetDevice(d), "hipSetDevice") && hip_ok(hipMalloc((void**)&d_packed[d], packed), "hipMalloc");
+      if (ok && d == 0) ok = hip_ok(hipMalloc((void**)&d_packed_all, packed * n), "hipMalloc");
+    }
+    for (int d = 0; d < n && ok; ++d) {
+      p3d_tile t{0, d * kStripeRows, W, H / n, kStripeRows, n};
+      ok = p3d_render_tile_device(scenes[d], &cfg, &t, (float*)d_packed[d], (int32_t*)(d_packed[d] + px_part * 12), d_part[d], streams[d], nullptr) == P3D_OK;
+      if (!ok) std::fprintf(stderr, "--verify render: %s\n", p3d_last_error());
+    }
+    if (ok) ok = nccl_ok(rccl.GroupStart(), "ncclGroupStart");
+    for (int d = 0; d < n && ok; ++d)
+      ok = nccl_ok(rccl.Gather(d_part[d], d == 0 ? d_all : nullptr, part, kNcclUint8, 0, comms[d], streams[d]), "ncclGather") &&
+           nccl_ok(rccl.Gather(d_packed[d], d == 0 ? d_packed_all : nullptr, packed, kNcclUint8, 0, comms[d], streams[d]), "ncclGather");
+    if (ok) ok = nccl_ok(rccl.GroupEnd(), "ncclGroupEnd");
+    for (int d = 0; d < n && ok; ++d) ok = hip_ok(hipSetDevice(d), "hipSetDevice") && hip_ok(hipStreamSynchronize(streams[d]), "hipStreamSynchronize") && p3d_scene_status(scenes[d]) == P3D_OK;
+    const size_t px = (size_t)W * H;
+    std::vector<float> g_rgb(px * 3), one_rgb(px * 3);
+    std::vector<int32_t> g_hit(px), one_hit(px);
+    std::vector<uint8_t> g_u8(px * 3), one_u8(px * 3), raw(packed * n), raw8(part * n);
+    if (ok) ok = hip_ok(hipSetDevice(0), "hipSetDevice") && hip_ok(hipMemcpy(raw.data(), d_packed_all, raw.size(), hipMemcpyDeviceToHost), "hipMemcpy") &&
+                 hip_ok(hipMemcpy(raw8.data(), d_all, raw8.size(), hipMemcpyDeviceToHost), "hipMemcpy");
+    for (int d = 0; d < n && ok; ++d)
+      for (int r = 0; r < H / n; ++r) {
+        const int y = ((r / kStripeRows) * n + d) * kStripeRows + r % kStripeRows;
+        const uint8_t* base = &raw[(size_t)d * packed];
+        std::memcpy(&g_rgb[(size_t)y * W * 3], base + (size_t)r * W * 12, (size_t)W * 12);
+        std::memcpy(&g_hit[(size_t)y * W], base + px_part * 12 + (size_t)r * W * 4, (size_t)W * 4);
+        std::memcpy(&g_u8[(size_t)y * row_bytes], &raw8[(size_t)d * part + (size_t)r * row_bytes], row_bytes);
+      }
+    if (ok) {  // the whole frame on GPU 0 alone, through the host-buffer call
+      p3d_tile full{0, 0, W, H, 0, 1};
+      ok = p3d_render_tile(scenes[0], &cfg, &full, one_rgb.data(), one_hit.data(), one_u8.data(), nullptr) == P3D_OK;
+      if (!ok) std::fprintf(stderr, "--verify single-GPU frame: %s\n", p3d_last_error());
+    }
+    for (int d = 0; d < n; ++d) { (void)hipSetDevice(d); if (d_packed[d]) (void)hipFree(d_packed[d]); }
+    (void)hipSetDevice(0);
+    if (d_packed_all) (void)hipFree(d_packed_all);
+    if (!ok) return 1;
+    size_t bad_rgb = 0, bad_hit = 0, bad_u8 = 0;
+    for (size_t i = 0; i < px * 3; ++i) {
+      uint32_t a, b;
+      std::memcpy(&a, &g_rgb[i], 4); std::memcpy(&b, &one_rgb[i], 4);
+      bad_rgb += a != b;
+      bad_u8 += g_u8[i] != one_u8[i];
+    }
+    for (size_t i = 0; i < px; ++i) bad_hit += g_hit[i] != one_hit[i];
+    const bool same = bad_rgb == 0 && bad_hit == 0 && bad_u8 == 0 && g_u8 == img;
+    std::printf("verify: frame gathered from %d GPU(s) vs the frame GPU 0 renders alone (float RGB, hit IDs, u8 image): %s", n, same ? "bit-identical\n" : "MISMATCH");
+    if (!same) std::printf(" (%zu colour words, %zu hit IDs, %zu bytes differ%s)\n", bad_rgb, bad_hit, bad_u8, g_u8 == img ? "" : "; the timed frame's u8 image differs from the verify frame's");
+    verdict = same ? 0 : 3;
+  }
   for (int d = 0; d < n; ++d) {
     (void)hipSetDevice(d);
     (void)hipFree(d_part[d]);
@@ -198,7 +262,7 @@ int render_multi_gpu(const p3d_scene_desc* desc, bool device_bvh, p3d_config cfg
   }
   (void)hipSetDevice(0);
   (void)hipFree(d_all);
-  return 0;
+  return verdict;
 }
 
 }  // namespace
@@ -208,7 +272,7 @@ int main(int argc, char** argv) {
   p3d_config_default(&cfg);
   std::string scene_path, skybox_dir, out = "RT_Output.png";  // main.cpp:851
   int res_w = 0, res_h = 0, device = 0, gpus = 0;
-  bool device_bvh = false;
+  bool device_bvh = false, verify = false;
   uint32_t load_flags = 0;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -237,6 +301,7 @@ int main(int argc, char** argv) {
     else if (a == "--device") device = std::atoi(next("--device"));
     else if (a == "--device-bvh") device_bvh = true;
     else if (a == "--gpus") gpus = std::atoi(next("--gpus"));
+    else if (a == "--verify") verify = true;
     else if (a[0] != '-') scene_path = a;
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
@@ -266,7 +331,7 @@ int main(int argc, char** argv) {
     if (!skybox_dir.empty()) { std::fprintf(stderr, "--gpus with --skybox is not wired up in this front end\n"); return 2; }
     std::vector<uint8_t> img((size_t)3 * W * H);
     double secs = 0;
-    if (render_multi_gpu(desc, device_bvh, cfg, gpus, img, &secs)) return 1;
+    if (const int rc = render_multi_gpu(desc, device_bvh, cfg, gpus, verify, img, &secs)) return rc;
     std::printf("Drawing finished!\n\nDone: %.2f (sec)\n", secs);
     std::printf("%d GPU(s): stripes of %d rows, one ncclGather of %zu bytes per GPU; second frame %.3f ms (render + gather)\n", gpus, kStripeRows,
                 (size_t)3 * W * (H / gpus), secs * 1e3);

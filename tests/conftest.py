@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the error-path tests shrink limits of single scenes through csrc/p3d_debug.h, which libp3d.so refuses unless asked at process start
+os.environ.setdefault("P3D_TEST_HOOKS", "1")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 SCENES = os.path.join(GOLDEN, "scenes")
 
@@ -15,6 +18,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")
     _ensure_built()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_sees_the_gpu_first():
+    """On the GPU box torch's HIP runtime is initialised before libp3d.so's first HIP call: in the other order (a test
+    selection whose first torch.cuda use comes after several library calls) torch reported `No HIP GPUs are available`."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+    yield
 
 
 def _ensure_built():

@@ -410,14 +410,13 @@ def test_sample_loop_backstop_is_an_error_not_a_darker_pixel():
     dev, _ = _pair(scene_path("path_balls.p3f"), res=(64, 64), grid=False)
     cfg = p3d.pathtrace_config(accel=p3d.ACCEL_BVH, spp_sqrt=4, max_depth=12, seed=3)
     good, _, _ = dev.render(cfg)
-    L = p3d.lib()
     try:
-        L.p3d_debug_set_trip_bound(5)
+        dev.debug_limits(trip_bound=5)
         with pytest.raises(p3d.P3DError) as e:
             dev.render(cfg)
         assert e.value.code == -4 and "trip bound" in str(e.value)
     finally:
-        L.p3d_debug_set_trip_bound(0)
+        dev.debug_limits()
     again, _, _ = dev.render(cfg)  # the flag was cleared with the error; the next call is clean
     assert (again.view(np.uint32) == good.view(np.uint32)).all()
 
@@ -435,11 +434,10 @@ def test_row_starts_are_certified_or_the_call_fails(scene, legacy, res):
     cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=4)
     full, full_hit, _ = dev.render(cfg)
     tiles = [p3d.stripe_tile(res, rank, 4, 8) for rank in range(4)] + [p3d.Tile(res[0] // 3, res[1] // 4, res[0] // 2, res[1] // 2, 0, 1)]
-    L = p3d.lib()
     fired = []
     for allowance in (1, 2, 3):
         try:
-            L.p3d_debug_set_halo_chain(allowance)
+            dev.debug_limits(halo_chain=allowance)
             n = 0
             for t in tiles:
                 try:
@@ -449,7 +447,7 @@ def test_row_starts_are_certified_or_the_call_fails(scene, legacy, res):
                     n += 1
             fired.append(n)
         finally:
-            L.p3d_debug_set_halo_chain(0)
+            dev.debug_limits()
     assert fired[0] > 0 and fired[0] >= fired[1] >= fired[2], fired  # fewer pixels allowed, more rows that cannot be certified
     for rank in range(4):
         rgb, hit, _ = dev.render(cfg, tile=tiles[rank])
@@ -477,16 +475,16 @@ def test_leftover_pool_that_runs_full_fails_or_falls_back_to_dense_records():
     assert_bit_identical((want, want_hit), (o_rgb, o_hit), "dense records")
     n = 192 * 192
     buf = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
-    L = p3d.lib()
     try:
-        L.p3d_debug_set_leftover_pool(2000)  # this frame leaves about 0.3 entries per pixel: 36 864 pixels need far more than that
+        dev.debug_limits(leftover_pool=2000)  # this frame leaves about 0.3 entries per pixel: 36 864 pixels need far more than that
         dev.render_device(cfg, dev.full_tile(), d_rgb=buf.data_ptr(), d_hit=buf.data_ptr() + n * 12)
         code = dev.status()
         msg = p3d.lib().p3d_last_error().decode()
-        again, again_hit, _ = dev.render(cfg)  # host-buffer call: falls back to dense records when the pool is too small
+        again, again_hit, again_st = dev.render(cfg)  # host-buffer call: falls back to dense records when the pool is too small
     finally:
-        L.p3d_debug_set_leftover_pool(0)
+        dev.debug_limits()
     assert code == -4 and "handoff_records" in msg, (code, msg)
+    assert again_st.handoff_dense_retry == 1  # ... and says so
     assert (again.view(np.uint32) == want.view(np.uint32)).all() and (again_hit == want_hit).all()
     assert dev.status() == 0
 
@@ -549,16 +547,15 @@ def test_hand_off_that_runs_out_of_rounds_is_an_error_also_without_stats():
     assert st.handoff_rounds >= 2
     n = 256 * 256
     buf = torch.empty(n * 16, dtype=torch.uint8, device="cuda")
-    L = p3d.lib()
     try:
-        L.p3d_debug_set_max_rounds(1)
+        dev.debug_limits(max_rounds=1)
         with pytest.raises(p3d.P3DError) as e:
             dev.render(cfg)
         assert e.value.code == -4 and "fixed point" in str(e.value)
         dev.render_device(cfg, dev.full_tile(), d_rgb=buf.data_ptr(), d_hit=buf.data_ptr() + n * 12)  # no stats: returns at once
         assert dev.status() == -4 and "fixed point" in p3d.lib().p3d_last_error().decode()
     finally:
-        L.p3d_debug_set_max_rounds(0)
+        dev.debug_limits()
     assert dev.status() == 0  # read and cleared
     again, _, _ = dev.render(cfg)
     assert (again.view(np.uint32) == good.view(np.uint32)).all()
@@ -777,9 +774,12 @@ def test_p3d_render_gpus_goes_through_rccl_and_writes_the_same_image(tmp_path):
     plain, multi = str(tmp_path / "plain.ppm"), str(tmp_path / "multi.ppm")
     r = subprocess.run(common + ["--out", plain], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    r = subprocess.run(common + ["--out", multi, "--gpus", "1"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run(common + ["--out", multi, "--gpus", "1", "--verify"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ncclGather" in r.stdout and "Image file created" in r.stdout
+    # --verify: float RGB + hit IDs through a second gather, compared bit for bit with the frame GPU 0 renders alone (the binary
+    # does the same at N = 8, exit code 3 on a mismatch)
+    assert "verify: frame gathered from 1 GPU(s)" in r.stdout and "bit-identical" in r.stdout, r.stdout
     assert open(plain, "rb").read() == open(multi, "rb").read()
     r = subprocess.run(common + ["--out", multi, "--gpus", "2"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "HIP device" in r.stderr
@@ -1242,8 +1242,23 @@ def test_scene_create_rejects_malformed_descriptors():
             L.p3d_scene_destroy(h)
         return rc
 
+    def share_a_child_pair(d, n, o, p, it):  # two inner nodes with the same children: a DAG, not a tree
+        inner = [i for i in range(good.n_bvh_nodes) if not (n[i].count_leaf & 0x80000000)]
+        a, b = inner[1], inner[2]
+        n[a].index = max(n[a].index, n[b].index)
+        n[b].index = n[a].index
+        assert n[a].index > max(a, b)
+
+    def overlap_child_pairs(d, n, o, p, it):  # (k+1, k+2) and (k+2, k+3): the shape the relabelling walk would re-visit exponentially
+        inner = [i for i in range(good.n_bvh_nodes) if not (n[i].count_leaf & 0x80000000) and n[i].index + 2 < good.n_bvh_nodes]
+        a = inner[1]
+        b = [i for i in inner if i > a][0]
+        n[b].index = n[a].index + 1
+
     assert try_create(lambda d, n, o, p, it: None) == 0
     bad = [
+        share_a_child_pair,
+        overlap_child_pairs,
         lambda d, n, o, p, it: setattr(p[3], "material", 99),
         lambda d, n, o, p, it: setattr(p[0], "type", 7),
         lambda d, n, o, p, it: setattr(n[0], "index", 1000),        # child pair beyond the array

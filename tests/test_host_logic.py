@@ -27,13 +27,17 @@ def test_library_exports_every_declared_symbol():
     lib = p3d.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.p3d_abi_version() == 3  # round 3: p3d_config.debug_view
+    assert lib.p3d_abi_version() == 4  # round 4: p3d_stats.handoff_dense_retry
+    # the test hooks are exported but live in a private header (csrc/p3d_debug.h), not in the drop-in boundary
+    assert "p3d_debug" not in hdr and hasattr(lib, "p3d_debug_scene_limits")
+    dbg = open(os.path.join(ROOT, "p3d-raytracer_amd", "csrc", "p3d_debug.h")).read()
+    assert "p3d_debug_scene_limits" in dbg
 
 
 def test_struct_layouts_match_the_header():
     assert C.sizeof(p3d.Prim) == 96 and C.sizeof(p3d.Material) == 64 and C.sizeof(p3d.Light) == 32
     assert C.sizeof(p3d.Camera) == 80 and C.sizeof(p3d.BvhNode) == 32
-    assert C.sizeof(p3d.Config) == 80 and C.sizeof(p3d.Tile) == 24 and C.sizeof(p3d.Stats) == 20 * 8
+    assert C.sizeof(p3d.Config) == 80 and C.sizeof(p3d.Tile) == 24 and C.sizeof(p3d.Stats) == 21 * 8
 
 
 def test_config_default_is_constants_h():
@@ -158,3 +162,50 @@ def test_handoff_predecessor_successor_scans(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
     assert int(out.stdout.split()[1]) > 100000
+
+
+def test_scene_create_rejects_a_bvh_that_is_not_a_tree():
+    """The descriptor's BVH is validated before anything touches a device (so this runs without one): a record with
+    two parents - shared or overlapping child pairs - passes the bounds checks but is a DAG; the upload's relabelling
+    walk would re-visit shared subtrees (Fibonacci-sized work for a chain of overlapping pairs).  Rejected, not hung."""
+    hs = p3d.HostScene(scene_path("balls_low.p3f"))
+    good = hs.desc(bvh=True, grid=False)
+    L = p3d.lib()
+
+    def create(mutate):
+        d = p3d.SceneDesc.from_buffer_copy(bytes(good))
+        nodes = (p3d.BvhNode * good.n_bvh_nodes)(*[good.bvh_nodes[i] for i in range(good.n_bvh_nodes)])
+        d.bvh_nodes = nodes
+        mutate(nodes)
+        h = C.c_void_p()
+        rc = L.p3d_scene_create(C.byref(d), 0, C.byref(h))
+        if rc == 0:
+            L.p3d_scene_destroy(h)
+        return rc, L.p3d_last_error().decode()
+
+    inner = [i for i in range(good.n_bvh_nodes) if not (good.bvh_nodes[i].count_leaf & 0x80000000)]
+    a, b = inner[1], inner[2]
+
+    def shared(n):
+        n[a].index = n[b].index = max(n[a].index, n[b].index)
+
+    def overlapping(n):
+        n[b].index = n[a].index + 1
+
+    for m in (shared, overlapping):
+        rc, msg = create(m)
+        assert rc == -1 and "more than one parent" in msg, (m.__name__, rc, msg)
+    # a synthetic chain of 60 overlapping pairs (node k -> children k+1, k+2): 2^40-ish walk if it were accepted
+    n_chain = 64
+    d = p3d.SceneDesc.from_buffer_copy(bytes(good))
+    nodes = (p3d.BvhNode * n_chain)()
+    for k in range(n_chain):
+        nodes[k].bmin[:] = [-1, -1, -1]
+        nodes[k].bmax[:] = [1, 1, 1]
+        if k + 2 < n_chain:
+            nodes[k].index, nodes[k].count_leaf = k + 1, 0
+        else:
+            nodes[k].index, nodes[k].count_leaf = 0, 0x80000000 | 1
+    d.bvh_nodes, d.n_bvh_nodes, d.bvh_max_depth = nodes, n_chain, n_chain
+    h = C.c_void_p()
+    assert L.p3d_scene_create(C.byref(d), 0, C.byref(h)) == -1 and "more than one parent" in L.p3d_last_error().decode()
