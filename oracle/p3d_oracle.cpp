@@ -633,7 +633,9 @@ void Grid::build(const Scene& s) {  // grid.cpp:3-68, bounds grid.cpp:211-259
 // ---------------------------------------------------------------------------
 // Per-thread tracing context: the BVH member stack (bvh.cpp:86), RNG, counters.
 // ---------------------------------------------------------------------------
-struct Ctx {
+// One per thread.  Its counters are bumped at every node and primitive test: each Ctx gets cache lines of its own (two
+// threads' counters on one line would bounce it between their cores for the whole render).
+struct alignas(128) Ctx {
   const Scene* sc;
   orc_config cfg;
   std::vector<StackItem> hit_stack;
@@ -1370,13 +1372,17 @@ void rebuild_camera(Scene& S, int rx, int ry) {
 void render_rows(Ctx& cx, int x0, int y0, int w, int h, std::atomic<int>& next_row, float* rgb,
                  int32_t* hit, uint8_t* rgb8, int repeat = 1) {
   const long long rows = (long long)h * repeat;  // timing runs render the tile `repeat` times with one thread pool
-  for (long long i = next_row.fetch_add(1, std::memory_order_relaxed); i < rows; i = next_row.fetch_add(1, std::memory_order_relaxed)) {
-    const int r = (int)(i % h);
-    int y = y0 + r;
-    for (int c = 0; c < w; c++) {
-      size_t k = (size_t)r * w + c;
-      render_pixel(cx, x0 + c, y, rgb ? rgb + 3 * k : nullptr, hit ? hit + k : nullptr,
-                   rgb8 ? rgb8 + 3 * k : nullptr);
+  // rows are handed out in blocks (one atomic per block, not per row) small enough that the last blocks still balance
+  const int block = rows >= 64 * 64 ? 4 : 1;
+  for (long long i0 = next_row.fetch_add(block, std::memory_order_relaxed); i0 < rows; i0 = next_row.fetch_add(block, std::memory_order_relaxed)) {
+    for (long long i = i0; i < i0 + block && i < rows; i++) {
+      const int r = (int)(i % h);
+      int y = y0 + r;
+      for (int c = 0; c < w; c++) {
+        size_t k = (size_t)r * w + c;
+        render_pixel(cx, x0 + c, y, rgb ? rgb + 3 * k : nullptr, hit ? hit + k : nullptr,
+                     rgb8 ? rgb8 + 3 * k : nullptr);
+      }
     }
   }
 }

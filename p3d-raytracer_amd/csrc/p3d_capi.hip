@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -104,8 +105,28 @@ inline uint32_t redo_lanes() {
   }();
   return v;
 }
+inline uint32_t round1_lanes() {  // list entries per wave of the round-1 launch (successors to re-check; P3D_ROUND1_LANES overrides)
+  static const uint32_t v = [] {
+    const char* e = getenv("P3D_ROUND1_LANES");
+    const int n = e ? atoi(e) : 64;
+    return (uint32_t)(n >= 1 && n <= 64 ? n : 64);
+  }();
+  return v;
+}
+inline bool takeover_rounds() {  // P3D_TAKEOVER=1: no launch of its own for the fixed-point rounds (measured: no gain, r04 experiments)
+  static const bool v = [] { const char* e = getenv("P3D_TAKEOVER"); return e && atoi(e) != 0; }();
+  return v;
+}
+inline uint32_t list_blocks() {  // workgroups of the round-1 work-list launch (P3D_LIST_BLOCKS overrides)
+  static const uint32_t v = [] {
+    const char* e = getenv("P3D_LIST_BLOCKS");
+    const int n = e ? atoi(e) : 256;
+    return (uint32_t)(n >= 1 ? n : 256);
+  }();
+  return v;
+}
 #ifdef P3D_ABLATION  // timing experiments only (profiles/r04/experiments): stages of the literal frame left out, frames WRONG
-inline uint32_t abl_skip() {  // P3D_ABL_SKIP: 1 = no check launch, 2 = no redo launch (round 0), 4 = no round 1 / persistent launch
+inline uint32_t abl_skip() {  // P3D_ABL_SKIP: 1 = no check launch, 2 = no redo launch (round 0), 4 = no round 1 launch, 8 = round 1 launched on an empty list
   static const uint32_t v = [] { const char* e = getenv("P3D_ABL_SKIP"); return e ? (uint32_t)atoi(e) : 0u; }();
   return v;
 }
@@ -687,7 +708,8 @@ int finish_stats(p3d_scene* s, hipStream_t st, p3d_stats* stats, bool literal) {
   if (literal) {
     uint32_t c[kHoNumCounters];
     P3D_HIP(hipMemcpy(c, s->ho_counters.p, sizeof(c), hipMemcpyDeviceToHost));
-    stats->handoff_checked = c[kHoChecked]; stats->handoff_redone = c[kHoRedone]; stats->handoff_rounds = c[kHoRounds] + (c[kHoRound0] ? 1 : 0);
+    if (getenv("P3D_PRINT_HANDOFF")) std::fprintf(stderr, "handoff: checked %u redone %u rounds %u pool %u lists A %u B %u C %u D %u check_n %u round0 %u round1 %u\n", c[kHoChecked], c[kHoRedone], c[kHoRounds], c[kHoPoolTop], c[kHoListA], c[kHoListB], c[kHoListC], c[kHoListD], c[kHoCheckN], c[kHoRound0], c[kHoRound1]);
+    stats->handoff_checked = c[kHoChecked]; stats->handoff_redone = c[kHoRedone]; stats->handoff_rounds = c[kHoRounds] + (c[kHoRound0] ? 1 : 0) + (c[kHoRound1] ? 1 : 0);
   }
   return check_status(s);
 }
@@ -1109,13 +1131,20 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       H.list_in = ho_list[round]; H.n_in = ho_counters + kHoListA + round;
       H.list_out = ho_list[round + 1]; H.n_out = ho_counters + kHoListA + round + 1;
       H.persistent = round == 2 ? 1u : 0u;
+      H.takeover = takeover_rounds() && round == 1 ? 1u : 0u;  // (experiment, off: see Handoff::takeover)
+      if (takeover_rounds() && round == 2) continue;
       H.round_base = (uint32_t)round;
       // round 0 renders unrelated deep pixels again; entries per wave: see P3D_REDO_LANES above
-      H.lanes = round == 0 ? redo_lanes() : kBlock;
-      const uint32_t blocks = round == 2 ? 1u : wide;
+      H.lanes = round == 0 ? redo_lanes() : round1_lanes();
+      // (round >= 1 works through the successors of units whose leftover changed, a few thousand list entries at most: a small
+      // grid with a grid-stride loop - 16 384 workgroups that find nothing take 25 us to come and go, a lone frame waits for them)
+      const uint32_t blocks = round == 2 ? 1u : (round == 1 ? std::min(wide, list_blocks()) : wide);
       P.level_stride = blocks * kBlock;
       P.tile_blocks = blocks;
+      const uint32_t real_cap = H.list_cap;
+      if (abl_skip() & 8u) H.list_cap = 0;  // (ablation: the launch happens, every workgroup finds an empty list)
       const hipError_t e = launch_literal(2, ghosts, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
+      H.list_cap = real_cap;
       if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("hand-off kernel launch: ") + hipGetErrorString(e));
     }
     if (want_counts) {
