@@ -1,5 +1,5 @@
 #!/bin/bash
-# build/ab_var.sh NAME... : bench loop (no CPU baseline) for the round-2 tree, HEAD and the named variant libraries, alternating
+# ab_var.sh NAME... (run from the repo root): bench loop (no CPU baseline) for a reference tree under build/r02tree (mktree.sh), HEAD and the named variant libraries, alternating
 out=$PWD/gpurun_out/ab_var; rm -rf $out; mkdir -p $out
 for rep in ${REPS:-1 2}; do
   (cd build/r02tree && python3 bench.py --no-cpu-baseline --steps ${STEPS:-200} --warmup 20 2>$out/r02.err | tail -1 > $out/00_r02_$rep.json)

@@ -2,7 +2,8 @@
 """build/mkexp.py NAME edit[,edit...] -> build/exp_NAME (patched copy of csrc/) ; edits are named below"""
 import sys, os, shutil, re
 name, edits = sys.argv[1], sys.argv[2].split(',')
-src = '/root/repo/p3d-raytracer_amd/csrc'; dst = '/root/repo/build/exp_' + name
+ROOT = os.environ.get('GRAFT_REPO_ROOT') or os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+src = ROOT + '/p3d-raytracer_amd/csrc'; dst = ROOT + '/build/exp_' + name
 shutil.rmtree(dst, ignore_errors=True); shutil.copytree(src, dst, ignore=shutil.ignore_patterns('*.o'))
 def sub(fn, old, new, count=1):
     p = os.path.join(dst, fn); s = open(p).read()
