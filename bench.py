@@ -190,9 +190,13 @@ def main():
     n_local = tile.w * tile.h
     stream = torch.cuda.current_stream()
     # frames in flight (N = 1): frame i is rendered by scene i % nfl on stream i % nfl into output buffers of its own
-    nfl = max(1, args.frames_in_flight if args.frames_in_flight is not None else (4 if not dist_on else 1))
+    # N > 1: two (one per gather slot) - every rank renders frame k + 1 on its second device scene and stream while frame k's
+    # slowest tiles finish and its gather runs.  A rank's stripes are a short launch, as long as its slowest waves whatever the
+    # work in it: rank 0 of 8 of the configs[3] frame takes 3.45 ms alone and 2.09 ms per frame with two in flight
+    # (an even share of the frame: 1.94 ms) - profiles/r04/experiments/README.md section 8.
+    nfl = max(1, args.frames_in_flight if args.frames_in_flight is not None else (4 if not dist_on else 2))
     if dist_on:
-        nfl = 1
+        nfl = min(nfl, 2)  # (the gather is double-buffered: one scene and stream per slot)
     # (slot 0 stays on the default stream: HIP spreads streams over 4 hardware queues, the default stream has one to
     # itself and the pool streams share the other three — a fourth pool stream would queue behind the first one's launches)
     flight = [(dev, stream)] + [(p3d.DeviceScene(hs, bvh=True, device=dev_index), torch.cuda.Stream()) for _ in range(nfl - 1)]
@@ -212,21 +216,25 @@ def main():
     in_flight = [0, 0]    # frames of the batch a pending gather carries
     sent_seq = [0, 0]     # order in which the slots' collectives were launched
     last_frame = [None]   # (slot, index) of the newest frame assembled on rank 0
+    assembled = [0, 0]    # frames of the batch last assembled from each slot
     pick = (lambda pair: pair[1]) if gather == "u8" else (lambda pair: pair[0])
     gdev = "cpu" if host_staged else "cuda"
     # (every rank keeps receive buffers: only rank 0 uses them unless the backend forces all_gather)
     gathered = ([[torch.empty(pick(bufs[0]).shape, dtype=torch.uint8, device=gdev) for _ in range(world)] for _ in range(2)]
                 if dist_on else None)
-    frame8 = torch.empty((B, res, res, 3), dtype=torch.uint8, device=gdev) if rank == 0 and dist_on else None
-    frame_rgb = torch.empty((B, res, res, 3), dtype=torch.float32, device=gdev) if rank == 0 and dist_on else None
-    frame_hit = torch.empty((B, res, res), dtype=torch.int32, device=gdev) if rank == 0 and dist_on else None
+    # (one assembled frame per gather slot: the two slots' de-interleave copies run on different streams)
+    asm = rank == 0 and dist_on
+    frame8 = [torch.empty((B, res, res, 3), dtype=torch.uint8, device=gdev) if asm and gather == "u8" else None for _ in range(2)]
+    frame_rgb = [torch.empty((B, res, res, 3), dtype=torch.float32, device=gdev) if asm and gather != "u8" else None for _ in range(2)]
+    frame_hit = [torch.empty((B, res, res), dtype=torch.int32, device=gdev) if asm and gather != "u8" else None for _ in range(2)]
 
     def assemble(slot):
         if gather == "u8":
-            p3d.assemble_frame8(gathered[slot], (res, res), world, stripe_h, frame8, batch=B)
+            p3d.assemble_frame8(gathered[slot], (res, res), world, stripe_h, frame8[slot], batch=B)
         else:
-            p3d.assemble_frame(gathered[slot], (res, res), world, stripe_h, frame_rgb, frame_hit, batch=B)
-        last_frame[0] = in_flight[slot] - 1
+            p3d.assemble_frame(gathered[slot], (res, res), world, stripe_h, frame_rgb[slot], frame_hit[slot], batch=B)
+        last_frame[0] = (slot, in_flight[slot] - 1)
+        assembled[slot] = in_flight[slot]
 
     def render_into(pair, tile_, cfg_, stats=None, frame=0, scene=None, on=None):
         packed, u8 = pair
@@ -235,31 +243,36 @@ def main():
         (scene or dev).render_device(cfg_, tile_, d_rgb=base_, d_hit=base_ + n_px * 12, d_rgb8=u8.data_ptr() + frame * n_px * 3,
                                      stream=(on or stream).cuda_stream, stats=stats)
 
+    def slot_ctx(slot):  # N > 1: slot k renders on scene k and stream k; its collective and its de-interleave are ordered on that stream
+        return torch.cuda.stream(flight[slot % nfl][1])
+
     def finish(slot):  # the collective of this slot has to be complete before the buffer is reused
         if handles[slot] is not None:
-            handles[slot].wait()
-            if rank == 0:
-                assemble(slot)
+            with slot_ctx(slot):
+                handles[slot].wait()
+                if rank == 0:
+                    assemble(slot)
             handles[slot] = None
 
     def send(slot):
         if dist_on and filled[slot]:
-            payload = pick(bufs[slot]).cpu() if host_staged else pick(bufs[slot])
-            handles[slot], _ = p3d.gather_frame(payload, (res, res), rank, world, stripe_h, 0, gathered[slot], async_op=True)
+            with slot_ctx(slot):
+                payload = pick(bufs[slot]).cpu() if host_staged else pick(bufs[slot])
+                handles[slot], _ = p3d.gather_frame(payload, (res, res), rank, world, stripe_h, 0, gathered[slot], async_op=True)
             in_flight[slot], filled[slot] = filled[slot], 0
             sent_seq[slot] = max(sent_seq) + 1
 
     flight_bufs = [bufs[0]] + [new_bufs() for _ in range(nfl - 1)]
 
     def step(i, cfg_):
-        if nfl > 1:  # one GPU: nothing to gather; the frame goes to the scene, stream and buffers of its slot
+        if nfl > 1 and not dist_on:  # one GPU: nothing to gather; the frame goes to the scene, stream and buffers of its slot
             k = i % nfl
             render_into(flight_bufs[k], tile, cfg_, scene=flight[k][0], on=flight[k][1])
             return
         slot, f = (i // B) & 1, i % B
         if f == 0:
             finish(slot)
-        render_into(bufs[slot], tile, cfg_, frame=f)
+        render_into(bufs[slot], tile, cfg_, frame=f, scene=flight[slot % nfl][0], on=flight[slot % nfl][1])
         filled[slot] += 1
         if f == B - 1:
             send(slot)
@@ -310,7 +323,7 @@ def main():
 
     # what the timed frames left in their slots must be, bit for bit, the frame one scene renders on its own
     flight_check = None
-    if nfl > 1:
+    if nfl > 1 and not dist_on:
         frames = [(b[0].clone(), b[1].clone()) for b in flight_bufs[:min(nfl, args.steps)]]
         render_into(bufs[1], tile, cfg)
         torch.cuda.synchronize()
@@ -381,12 +394,15 @@ def main():
         render_into(ref_pair, full, cfg)
         torch.cuda.synchronize()
         ref_packed, ref_u8 = ref_pair[0].to(gdev), ref_pair[1].to(gdev)
-        k = last_frame[0]
-        if gather == "u8":
-            ok = bool(torch.equal(frame8[k].reshape(-1), ref_u8))
-        else:
-            ok = bool(torch.equal(frame_rgb[k].reshape(-1).view(torch.int32), ref_packed[: res * res * 12].view(torch.int32))
-                      and torch.equal(frame_hit[k].reshape(-1), ref_packed[res * res * 12:].view(torch.int32)))
+        # ... every slot's last assembled frame (with two frames in flight: one per device scene and stream)
+        ok = True
+        for slot_ in range(2):
+            if gather == "u8":
+                ok = ok and all(bool(torch.equal(frame8[slot_][k].reshape(-1), ref_u8)) for k in range(assembled[slot_]))
+            else:
+                ok = ok and all(bool(torch.equal(frame_rgb[slot_][k].reshape(-1).view(torch.int32), ref_packed[: res * res * 12].view(torch.int32))
+                                     and torch.equal(frame_hit[slot_][k].reshape(-1), ref_packed[res * res * 12:].view(torch.int32))) for k in range(assembled[slot_]))
+        ok = ok and last_frame[0] is not None and all(sc_.status() == 0 for sc_, _ in flight)
         gather_check = "ok" if ok else "MISMATCH"
         # and what ONE GPU needs for the whole frame (outside the timed region, the other ranks idle): the N = 1 point of
         # THIS workload, so that the strong-scaling ratio can be read off one line (the driver's N = 1 run is cfg2)
@@ -458,8 +474,9 @@ def main():
                        "parallelism": "image rows in %d-row stripes, round-robin over %d GPU(s)%s"
                                       % (stripe_h, world,
                                          "; every frame's %s gathered to rank 0 over %s, %d frame(s) per collective, "
-                                         "double-buffered; gathered frame vs single-GPU frame: %s"
-                                         % ("u8 image" if gather == "u8" else "float RGB + hit IDs", "RCCL" if args.backend == "nccl" else "gloo (host-staged)", B, gather_check)
+                                         "double-buffered, %d frame(s) in flight per rank (one device scene and stream per gather slot); "
+                                         "gathered frame vs single-GPU frame: %s"
+                                         % ("u8 image" if gather == "u8" else "float RGB + hit IDs", "RCCL" if args.backend == "nccl" else "gloo (host-staged)", B, nfl, gather_check)
                                          if dist_on else "")},
             "value_note": "value = throughput of the timed loop (median of %d repeats of exactly --steps steps) with `frames_in_flight` frames "
                           "overlapping on as many device scenes and streams; value_single_frame / latency_ms_single_frame = ONE frame rendered "
