@@ -453,11 +453,19 @@ int p3d_host_scene_desc(p3d_host_scene* hs, int build_bvh, int build_grid,
  * questions should ask them in one batch: p3d_trace_closest / p3d_trace_any / p3d_object_intercepts /
  * p3d_object_normal / p3d_skybox_color take n rays per call. */
 int p3d_host_scene_bind_device(p3d_host_scene* hs, p3d_scene* scene);
-/* 1 if the `.p3f` had an `env <dir>` line (scene.cpp:605-610) and the six faces were found as binary PPMs
- * (<dir>/{right,left,top,bottom,front,back}.ppm, relative to the working directory or to the scene file;
- * scenes/skybox_to_ppm.py converts the reference's JPEG folder), 0 otherwise: JPEG decoding (DevIL in the
- * reference) is not part of this library. */
+/* 1 if a cubemap is loaded: the `.p3f` had an `env <dir>` line (scene.cpp:605-610) and the folder was found (relative to
+ * the working directory, as in the reference, or next to the scene file), or p3d_host_scene_load_skybox was called. */
 int p3d_host_scene_has_skybox(p3d_host_scene* hs);
+/* Scene::LoadSkybox (scene.cpp:329-377): <sky_dir>/{right,left,top,bottom,front,back}.jpg, decoded by the library
+ * (baseline JPEG - sequential DCT, Huffman, 8 bit, grey or YCbCr with 1x1 / 2x1 / 2x2 luma sampling - following the IJG
+ * library's default path: the six shipped faces come out byte for byte as PIL's libjpeg-turbo decodes them; DevIL's own
+ * version is unpinned in the reference).  A face that is not there as .jpg is read from a binary .ppm of that name.
+ * P3D_ERR_IO names the face that could not be read (the reference exit(0)s, scene.cpp:354-357).  The faces go to the
+ * device scene with p3d_host_scene_bind_device. */
+int p3d_host_scene_load_skybox(p3d_host_scene* hs, const char* sky_dir);
+/* Scene::skybox_img[face] (scene.h:218-223; RIGHT 0, LEFT 1, TOP 2, BOTTOM 3, FRONT 4, BACK 5): the decoded RGB bytes,
+ * bottom row first (IL_ORIGIN_LOWER_LEFT, scene.cpp:344-345), owned by the host scene. */
+int p3d_host_scene_skybox_face(p3d_host_scene* hs, int face, const uint8_t** img, uint32_t* res_x, uint32_t* res_y);
 
 #ifdef __cplusplus
 }

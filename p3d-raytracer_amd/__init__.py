@@ -36,7 +36,7 @@ EXPORTS = [
     "p3d_scene_status", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
     "p3d_trace_closest", "p3d_trace_any", "p3d_host_scene_load", "p3d_host_scene_destroy",
     "p3d_host_scene_set_resolution", "p3d_host_scene_set_lens", "p3d_host_scene_replicate_lights",
-    "p3d_host_scene_desc", "p3d_host_scene_bind_device", "p3d_host_scene_has_skybox",
+    "p3d_host_scene_desc", "p3d_host_scene_bind_device", "p3d_host_scene_has_skybox", "p3d_host_scene_load_skybox", "p3d_host_scene_skybox_face",
 ]
 
 
@@ -170,6 +170,8 @@ def lib():
         L.p3d_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(C.c_void_p)]
         L.p3d_host_scene_bind_device.argtypes = [C.c_void_p, C.c_void_p]
         L.p3d_host_scene_has_skybox.argtypes = [C.c_void_p]
+        L.p3d_host_scene_load_skybox.argtypes = [C.c_void_p, C.c_char_p]
+        L.p3d_host_scene_skybox_face.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.p3d_scene_destroy.argtypes = [C.c_void_p]
         L.p3d_scene_set_skybox.argtypes = [C.c_void_p, C.POINTER(SkyboxDesc)]
         L.p3d_render_tile.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(Tile), C.c_void_p, C.c_void_p,
@@ -254,8 +256,19 @@ class HostScene:
         _check(self._L.p3d_host_scene_replicate_lights(self._h, int(spp_sqrt), float(light_side)))
 
     def has_skybox(self):
-        """The loader found the cubemap of the scene's `env` line as six binary PPM faces (p3d_host_scene_has_skybox)."""
+        """A cubemap is loaded: the folder of the scene's `env` line was found, or load_skybox was called (p3d_host_scene_has_skybox)."""
         return bool(self._L.p3d_host_scene_has_skybox(self._h))
+
+    def load_skybox(self, sky_dir):
+        """Scene::LoadSkybox (scene.cpp:329-377): the six faces of `sky_dir` as .jpg (decoded by the library) or .ppm."""
+        _check(self._L.p3d_host_scene_load_skybox(self._h, os.fsencode(sky_dir)))
+
+    def skybox_face(self, face):
+        """Scene::skybox_img[face] as the library decoded it: (res_y, res_x, 3) uint8, bottom row first."""
+        img = C.POINTER(C.c_uint8)()
+        w, h = C.c_uint32(), C.c_uint32()
+        _check(self._L.p3d_host_scene_skybox_face(self._h, int(face), C.byref(img), C.byref(w), C.byref(h)))
+        return np.ctypeslib.as_array(img, shape=(h.value, w.value, 3)).copy()
 
     def desc(self, bvh=False, grid=False):
         p = C.POINTER(SceneDesc)()

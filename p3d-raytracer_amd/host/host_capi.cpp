@@ -175,6 +175,17 @@ int p3d_host_scene_desc(p3d_host_scene* hs, int build_bvh, int build_grid, const
 
 int p3d_host_scene_has_skybox(p3d_host_scene* hs) { return hs && hs->scene.SkyboxLoaded() ? 1 : 0; }
 
+int p3d_host_scene_load_skybox(p3d_host_scene* hs, const char* sky_dir) {
+  if (!hs || !sky_dir) return p3d::fail(P3D_ERR_INVALID, "p3d_host_scene_load_skybox: null argument");
+  return hs->scene.LoadSkybox(sky_dir) ? P3D_OK : P3D_ERR_IO;  // (the message names the face that could not be read)
+}
+
+int p3d_host_scene_skybox_face(p3d_host_scene* hs, int face, const uint8_t** img, uint32_t* res_x, uint32_t* res_y) {
+  if (!hs || !img) return p3d::fail(P3D_ERR_INVALID, "p3d_host_scene_skybox_face: null argument");
+  *img = hs->scene.SkyboxFace(face, res_x, res_y);
+  return *img ? P3D_OK : p3d::fail(P3D_ERR_INVALID, "p3d_host_scene_skybox_face: no cubemap loaded, or face not in 0..5");
+}
+
 int p3d_host_scene_bind_device(p3d_host_scene* hs, p3d_scene* scene) {
   if (!hs) return p3d::fail(P3D_ERR_INVALID, "p3d_host_scene_bind_device: null argument");
   if (hs->bvh) hs->bvh->bindDevice(scene);

@@ -11,8 +11,9 @@
 //              [--stack literal|per_pixel]   p3d_config.stack_mode (default literal: the reference's one hit_stack)
 //              [--device-bvh]   build a linear BVH on the GPU instead of the reference's tree on the host
 //                               (p3d_scene_create_device_bvh: same closest hits, shadow feelers may differ)
-//              [--skybox DIR]   DIR/{right,left,top,bottom,front,back}.ppm (binary P6; convert the
-//                               reference's JPEGs once with scenes/skybox_to_ppm.py) -> SKYBOX true
+//              [--skybox DIR]   DIR/{right,left,top,bottom,front,back}.jpg (baseline JPEG, decoded by the library as
+//                               Scene::LoadSkybox asks DevIL to; .ppm accepted too) -> SKYBOX true.  A scene's own
+//                               `env <dir>` line does the same when the folder is found.
 //              [--gpus N]       the frame's rows dealt to N GPUs of this node in 8-row stripes (one device scene each, this
 //                               one process driving them), every GPU's part of the image brought to GPU 0 by ONE
 //                               ncclGather over xGMI (RCCL, loaded at run time), de-interleaved on the host.  Same image
@@ -87,24 +88,6 @@ bool save_png(const std::string& path, const std::vector<uint8_t>& rgb8, int w, 
   chunk("IDAT", z.data(), (uint32_t)zlen);
   chunk("IEND", nullptr, 0);
   return (bool)f;
-}
-
-// One cubemap face from a binary PPM, stored bottom row first like DevIL's lower-left origin
-// (scene.cpp:344-345).  JPEG decoding is deliberately not part of this program.
-bool load_ppm_face(const std::string& path, std::vector<uint8_t>& bytes, uint32_t& w, uint32_t& h) {
-  std::ifstream f(path, std::ios::binary);
-  if (!f) return false;
-  std::string magic;
-  int maxv = 0;
-  f >> magic >> w >> h >> maxv;
-  if (magic != "P6" || maxv != 255 || w == 0 || h == 0) return false;
-  f.get();
-  std::vector<uint8_t> top_down((size_t)w * h * 3);
-  f.read(reinterpret_cast<char*>(top_down.data()), (std::streamsize)top_down.size());
-  if (!f) return false;
-  bytes.resize(top_down.size());
-  for (uint32_t y = 0; y < h; ++y) std::memcpy(&bytes[(size_t)y * w * 3], &top_down[(size_t)(h - 1 - y) * w * 3], (size_t)w * 3);
-  return true;
 }
 
 // ---- --gpus N: one process, N devices, one RCCL gather per frame (ncclGather, rccl.h:745) ----
@@ -354,19 +337,8 @@ int main(int argc, char** argv) {
     cfg.skybox = 1;
   }
   if (!skybox_dir.empty()) {  // Scene::LoadSkybox (scene.cpp:329-377) + SKYBOX true (constants.h:30)
-    static const char* names[6] = {"right", "left", "top", "bottom", "front", "back"};
-    std::vector<uint8_t> bytes[6];
-    p3d_skybox_desc sky{};
-    for (int i = 0; i < 6; ++i) {
-      uint32_t w = 0, h = 0;
-      if (!load_ppm_face(skybox_dir + "/" + names[i] + ".ppm", bytes[i], w, h)) {
-        std::fprintf(stderr, "cannot read %s/%s.ppm\n", skybox_dir.c_str(), names[i]);
-        return 1;
-      }
-      std::printf("Skybox face %d: Image sucessfully loaded.\n", i);  // scene.cpp:352
-      sky.face[i].img = bytes[i].data(); sky.face[i].res_x = w; sky.face[i].res_y = h; sky.face[i].bpp = 3;
-    }
-    if (p3d_scene_set_skybox(scene, &sky) != P3D_OK) return die("skybox");
+    if (p3d_host_scene_load_skybox(hs, skybox_dir.c_str()) != P3D_OK) return die("skybox");
+    if (p3d_host_scene_bind_device(hs, scene) != P3D_OK) return die("skybox");
     cfg.skybox = 1;
   }
   const auto t_build1 = std::chrono::high_resolution_clock::now();

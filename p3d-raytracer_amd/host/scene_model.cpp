@@ -1,5 +1,6 @@
 // scene_model.cpp — shape constructors, camera frame and the .p3f loader of the host side.
 #include "scene_model.hpp"
+#include "jpeg_decode.hpp"
 
 #include "p3d.h"
 #include "p3d_error.hpp"
@@ -9,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <functional>
 #include <map>
 #include <string>
@@ -148,24 +150,38 @@ bool Scene::bindDevice(::p3d_scene* dev) {
   return true;
 }
 
-// scene.cpp:329-377 with binary PPM faces instead of DevIL-decoded JPEGs (see the header)
+// scene.cpp:329-377: <dir>/{right,left,top,bottom,front,back}.jpg, decoded here (host/jpeg_decode.cpp: baseline JPEG, the
+// six shipped faces byte for byte what PIL's libjpeg-turbo gives) where the reference asks DevIL; a face that is not there as
+// .jpg is taken from a binary PPM of the same name (what round 3 needed scenes/skybox_to_ppm.py for).
 bool Scene::LoadSkybox(const char* sky_dir) {
   static const char* maps[6] = {"/right", "/left", "/top", "/bottom", "/front", "/back"};  // scene.cpp:333
   for (int f = 0; f < 6; ++f) {
-    const std::string path = std::string(sky_dir) + maps[f] + ".ppm";
-    std::ifstream file(path, std::ios::binary);
-    std::string magic;
+    std::vector<uint8_t> top_down;
     uint32_t w = 0, h = 0;
-    int maxv = 0;
-    if (file) file >> magic >> w >> h >> maxv;
-    if (!file || magic != "P6" || maxv != 255 || w == 0 || h == 0) {
-      fail(P3D_ERR_IO, "Scene::LoadSkybox: cannot read " + path + " (binary PPM; scenes/skybox_to_ppm.py converts the JPEG folder)");
-      return false;
+    const std::string jpg = std::string(sky_dir) + maps[f] + ".jpg";
+    std::ifstream jfile(jpg, std::ios::binary);
+    if (jfile) {
+      const std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(jfile)), std::istreambuf_iterator<char>());
+      std::string why;
+      if (!jpeg_decode_rgb(bytes.data(), bytes.size(), top_down, w, h, why)) {
+        fail(P3D_ERR_IO, "Scene::LoadSkybox: " + jpg + ": " + why);
+        return false;
+      }
+    } else {
+      const std::string path = std::string(sky_dir) + maps[f] + ".ppm";
+      std::ifstream file(path, std::ios::binary);
+      std::string magic;
+      int maxv = 0;
+      if (file) file >> magic >> w >> h >> maxv;
+      if (!file || magic != "P6" || maxv != 255 || w == 0 || h == 0) {
+        fail(P3D_ERR_IO, "Scene::LoadSkybox: cannot read " + jpg + " nor " + path + " (baseline JPEG or binary PPM)");
+        return false;
+      }
+      file.get();
+      top_down.resize((size_t)w * h * 3);
+      file.read(reinterpret_cast<char*>(top_down.data()), (std::streamsize)top_down.size());
+      if (!file) { fail(P3D_ERR_IO, "Scene::LoadSkybox: short file " + path); return false; }
     }
-    file.get();
-    std::vector<uint8_t> top_down((size_t)w * h * 3);
-    file.read(reinterpret_cast<char*>(top_down.data()), (std::streamsize)top_down.size());
-    if (!file) { fail(P3D_ERR_IO, "Scene::LoadSkybox: short file " + path); return false; }
     Face& F = skybox_img[f];
     F.resX = w; F.resY = h; F.BPP = 3;
     F.img.resize(top_down.size());
@@ -306,10 +322,10 @@ bool Scene::load_p3f(const char* name, bool legacy_f11) {
          SetBackgroundColor(c);
        }},
       {"env", [&] {  // scene.cpp:605-610: LoadSkybox(<dir>) + SetSkyBoxFlg(true)
-         // The reference decodes <dir>/*.jpg through DevIL and exits if a face is missing.  This library decodes nothing:
-         // the faces are loaded when the folder holds them as binary PPMs (scenes/skybox_to_ppm.py), looked up relative
-         // to the working directory as the reference does and, failing that, next to the scene file; with no PPM folder
-         // the directory is only recorded (GetSkyboxDir) and a later LoadSkybox / p3d_scene_set_skybox supplies the faces.
+         // The reference decodes <dir>/*.jpg through DevIL and exits if a face is missing.  Here the folder is looked up relative
+         // to the working directory as the reference does and, failing that, next to the scene file; its faces are decoded by
+         // LoadSkybox (baseline JPEG, or binary PPM).  With no such folder the directory is only recorded (GetSkyboxDir) and a
+         // later LoadSkybox / p3d_scene_set_skybox supplies the faces.
          std::string dir;
          in >> dir;
          skyboxDir = dir;
@@ -318,7 +334,7 @@ bool Scene::load_p3f(const char* name, bool legacy_f11) {
          const size_t slash = beside.find_last_of('/');
          beside = slash == std::string::npos ? dir : beside.substr(0, slash + 1) + dir;
          for (const std::string& cand : {dir, beside}) {
-           if (!std::ifstream(cand + "/right.ppm", std::ios::binary).is_open()) continue;
+           if (!std::ifstream(cand + "/right.jpg", std::ios::binary).is_open() && !std::ifstream(cand + "/right.ppm", std::ios::binary).is_open()) continue;
            if (!LoadSkybox(cand.c_str())) stop = env_failed = true;  // faces present but unreadable: the reference would exit(0) here
            break;
          }

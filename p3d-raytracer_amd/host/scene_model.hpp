@@ -241,10 +241,17 @@ class Scene {
   bool GetSkyBoxFlg() const { return SkyBoxFlg; }
   void SetSkyBoxFlg(bool f) { SkyBoxFlg = f; }
   const std::string& GetSkyboxDir() const { return skyboxDir; }
-  // scene.cpp:329-377: the six faces <dir>/{right,left,top,bottom,front,back}.  The reference decodes JPEGs through
-  // DevIL; this library has no image decoder: the faces are read as binary PPMs (scenes/skybox_to_ppm.py converts a
-  // folder once) and kept bottom row first (IL_ORIGIN_LOWER_LEFT).  Uploaded to the bound device scene, now or at bindDevice.
+  // scene.cpp:329-377: the six faces <dir>/{right,left,top,bottom,front,back}.jpg.  The reference decodes them through
+  // DevIL; here host/jpeg_decode.cpp does (baseline JPEG; a face missing as .jpg is read from a binary .ppm of the same
+  // name).  Kept bottom row first (IL_ORIGIN_LOWER_LEFT).  Uploaded to the bound device scene, now or at bindDevice.
   bool LoadSkybox(const char* sky_dir);
+  // skybox_img[face] of scene.h:218-223: decoded RGB bytes (bottom row first) and size; nullptr before LoadSkybox
+  const uint8_t* SkyboxFace(int face, uint32_t* res_x, uint32_t* res_y) const {
+    if (!skybox_loaded || face < 0 || face > 5) return nullptr;
+    if (res_x) *res_x = skybox_img[face].resX;
+    if (res_y) *res_y = skybox_img[face].resY;
+    return skybox_img[face].img.data();
+  }
   bool SkyboxLoaded() const { return skybox_loaded; }
   Color GetSkyboxColor(Ray& r);  // scene.cpp:379-457, one lookup on the device (p3d_skybox_color)
   // The device scene that answers the ray queries of this scene's objects (p3d_scene_create of this scene's

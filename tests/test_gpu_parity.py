@@ -895,6 +895,43 @@ def test_env_line_loads_the_cubemap_when_the_faces_are_there(tmp_path):
     assert (rgb.view(np.uint32) == want.view(np.uint32)).all() and (hit == want_hit).all()
 
 
+def test_env_line_and_front_end_decode_the_shipped_jpeg_faces(tmp_path):
+    """The reference's default look from C++ alone: `env <dir>` names a folder of JPEG faces (scene.cpp:605-610, 329-377) and
+    the library decodes them (host/jpeg_decode.cpp) - same frame, bit for bit, as handing over the faces PIL decodes; and
+    `p3d_render --skybox DIR` on the scene as shipped writes the image `p3d_render` writes for the scene whose env line points
+    at the folder."""
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    sky = os.path.join(GOLDEN, "skybox")
+    src = open(scene_path("balls_low.p3f")).read()
+    scene = tmp_path / "with_env.p3f"
+    scene.write_text(src.replace("env skybox", "env " + sky))
+    hs = p3d.HostScene(str(scene))
+    assert hs.has_skybox()
+    hs.set_resolution(128, 128)
+    dev = p3d.DeviceScene(hs, bvh=True)
+    dev.bind_host()
+    cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=3, skybox=1)
+    rgb, hit, _ = dev.render(cfg)
+    ref = p3d.DeviceScene(hs, bvh=True)
+    ref.set_skybox(p3d.load_skybox_dir(sky))  # PIL
+    want, want_hit, _ = ref.render(cfg)
+    assert (rgb.view(np.uint32) == want.view(np.uint32)).all() and (hit == want_hit).all()
+    plain, _, _ = dev.render(p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=3))
+    assert (plain != rgb).any()  # the sky is in the picture (in the mirror spheres: the floor fills this view)
+    exe = os.path.join(ROOT, "p3d-raytracer_amd", "p3d_render")
+    subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe), "p3d_render"])
+    common = ["--whitted", "--accel", "bvh", "--depth", "3", "--aa", "0", "--res", "128", "128"]
+    a, b = str(tmp_path / "env.ppm"), str(tmp_path / "flag.ppm")
+    r = subprocess.run([exe, str(scene)] + common + ["--out", a], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Skybox face 5: Image sucessfully loaded." in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, scene_path("balls_low.p3f")] + common + ["--skybox", sky, "--out", b], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()
+    img = np.frombuffer(open(a, "rb").read()[-128 * 128 * 3:], np.uint8).reshape(128, 128, 3)[::-1]  # file rows are top-down
+    assert (img == (np.minimum(rgb * 255.99, 255.0)).astype(np.uint8)).all()  # u8fromfloat at GAMMA 1 (maths.h:81-86)
+
+
 @pytest.mark.parametrize("accel", [p3d.ACCEL_NONE, p3d.ACCEL_GRID, p3d.ACCEL_BVH])
 def test_debug_views_of_constants_h(accel):
     """TEST_INTERSECT (constants.h:18: every hit is Color(1,0,0), main.cpp:156 and :359) and DEPTH_MAP (constants.h:33:

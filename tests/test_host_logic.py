@@ -209,3 +209,68 @@ def test_scene_create_rejects_a_bvh_that_is_not_a_tree():
     d.bvh_nodes, d.n_bvh_nodes, d.bvh_max_depth = nodes, n_chain, n_chain
     h = C.c_void_p()
     assert L.p3d_scene_create(C.byref(d), 0, C.byref(h)) == -1 and "more than one parent" in L.p3d_last_error().decode()
+
+
+def test_library_decodes_the_shipped_jpeg_faces_like_the_fixture(tmp_path):
+    """Scene::LoadSkybox (scene.cpp:329-377) asks DevIL for the six JPEG faces; the library decodes them itself
+    (host/jpeg_decode.cpp: baseline JPEG along the IJG library's default path).  DevIL's version is unpinned in the
+    reference, so the bar is the decoder the fixtures were made with: tests/golden/skybox/decoded.json (PIL 12.2,
+    libjpeg-turbo) - byte for byte, tolerance 0, on all six shipped faces."""
+    import hashlib
+    import json
+    sky = os.path.join(ROOT, "tests", "golden", "skybox")
+    want = json.load(open(os.path.join(sky, "decoded.json")))["faces"]
+    hs = p3d.HostScene(scene_path("balls_low.p3f"))
+    assert not hs.has_skybox()  # `env skybox` is relative to the working directory / the scene file: not there
+    hs.load_skybox(sky)
+    assert hs.has_skybox()
+    for i, name in enumerate(p3d.SKYBOX_FACE_FILES):
+        face = hs.skybox_face(i)  # bottom row first (IL_ORIGIN_LOWER_LEFT)
+        assert face.shape == (2048, 2048, 3)
+        assert hashlib.sha256(np.ascontiguousarray(face[::-1]).tobytes()).hexdigest() == want[name]["decoded_rgb_sha256"], name
+    with pytest.raises(p3d.P3DError) as e:
+        p3d.HostScene(scene_path("balls_low.p3f")).load_skybox(str(tmp_path))
+    assert e.value.code == -5 and "right" in str(e.value)  # P3D_ERR_IO, names the face
+
+
+def test_jpeg_decoder_matches_pil_on_other_baseline_files_and_refuses_the_rest(tmp_path):
+    """Sampling factors 1x1 / 2x1 / 2x2, grey, sizes that are not whole MCUs, restart intervals: byte for byte what PIL
+    decodes.  Progressive files and garbage are refused with a message, not decoded wrongly."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:61, 0:83]
+    base = np.stack([(xx * 3 + yy) % 256, (yy * 5 + 40 * np.sin(xx / 7.0)) % 256, (xx * yy // 9) % 256], -1).astype(np.uint8)
+    base[20:40, 30:60] = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    hs = p3d.HostScene(scene_path("balls_low.p3f"))
+
+    def through_library(make):
+        folder = tmp_path / ("sky%d" % through_library.n)
+        through_library.n += 1
+        folder.mkdir()
+        for name in p3d.SKYBOX_FACE_FILES:
+            make(str(folder / (name + ".jpg")))
+        hs.load_skybox(str(folder))
+        return hs.skybox_face(0)[::-1], np.asarray(Image.open(str(folder / "right.jpg")).convert("RGB"))
+    through_library.n = 0
+
+    cases = [dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=2, quality=35), dict(subsampling=0, quality=98)]
+    for size in ((83, 61), (16, 16), (17, 9), (1, 1), (33, 2)):
+        for kw in cases:
+            img = Image.fromarray(base[:size[1], :size[0]])
+            got, ref = through_library(lambda p: img.save(p, "JPEG", **kw))
+            assert got.shape == ref.shape and (got == ref).all(), (size, kw, int(np.abs(got.astype(int) - ref).max()))
+    grey = Image.fromarray(base[..., 0])
+    got, ref = through_library(lambda p: grey.save(p, "JPEG", quality=80))
+    assert (got == ref).all()
+    try:  # restart markers (Pillow >= 10.2)
+        img = Image.fromarray(base)
+        got, ref = through_library(lambda p: img.save(p, "JPEG", subsampling=2, restart_marker_blocks=3))
+        assert (got == ref).all()
+    except TypeError:
+        pass
+    with pytest.raises(p3d.P3DError) as e:
+        through_library(lambda p: Image.fromarray(base).save(p, "JPEG", progressive=True))
+    assert "progressive" in str(e.value)
+    with pytest.raises(p3d.P3DError):
+        through_library(lambda p: open(p, "wb").write(b"\xff\xd8\xff\xe0 not a jpeg at all"))
