@@ -318,7 +318,12 @@ def main():
     render_into(bufs[0], tile, cfg, stats=cold)
     for sc_, st_ in flight[1:]:  # the other slots record their tile schedules outside the timed region too
         render_into(bufs[0], tile, cfg, stats=p3d.Stats(), scene=sc_, on=st_)
-    dts = sorted(timed_loop(cfg) for _ in range(TIMED_REPEATS))
+    def timed_repeats(cfg_):
+        """the timed loop up to TIMED_REPEATS times (fewer when one loop takes seconds: the heavy workloads), sorted"""
+        first = timed_loop(cfg_)
+        n = TIMED_REPEATS if first < 0.5 else (3 if first < 3.0 else 1)
+        return sorted([first] + [timed_loop(cfg_) for _ in range(n - 1)])
+    dts = timed_repeats(cfg)
     dt = dts[len(dts) // 2]
 
     # what the timed frames left in their slots must be, bit for bit, the frame one scene renders on its own
@@ -334,7 +339,8 @@ def main():
     # Launch durations inside the frame, live: HIP events of the library on the launch stream (p3d_stats.kernel_ms /
     # pass1_ms / handoff_ms), 16 frames after the timed region, smallest and mean.
     probes = []
-    for _ in range(16):
+    n_probes = 16 if dt / args.steps < 0.05 else 3  # (frames of seconds: three)
+    for _ in range(n_probes):
         st_ = p3d.Stats()
         render_into(bufs[0], tile, cfg, stats=st_)
         probes.append((st_.kernel_ms, st_.pass1_ms, st_.handoff_ms))
@@ -372,10 +378,10 @@ def main():
         render_into(bufs[0], tile, cfg_pp, stats=pp_cold, scene=fresh)
         for sc_, st_ in flight:
             render_into(bufs[0], tile, cfg_pp, stats=p3d.Stats(), scene=sc_, on=st_)
-        dts_pp = sorted(timed_loop(cfg_pp) for _ in range(TIMED_REPEATS))
+        dts_pp = timed_repeats(cfg_pp)
         dt_pp = dts_pp[len(dts_pp) // 2]
         pk = []
-        for _ in range(16):
+        for _ in range(n_probes):
             st_ = p3d.Stats()
             render_into(bufs[0], tile, cfg_pp, stats=st_)
             pk.append(st_.kernel_ms)
@@ -480,7 +486,7 @@ def main():
                                          if dist_on else "")},
             "value_note": "value = throughput of the timed loop (median of %d repeats of exactly --steps steps) with `frames_in_flight` frames "
                           "overlapping on as many device scenes and streams; value_single_frame / latency_ms_single_frame = ONE frame rendered "
-                          "alone (HIP events inside the library, mean of 16 frames)" % TIMED_REPEATS,
+                          "alone (HIP events inside the library, mean of %d frames)" % (len(dts), n_probes),
             "frame": {"kernel_ms": round(kernel_ms, 4), "pass1_ms": round(pass1_ms, 4), "handoff_ms": round(handoff_ms, 4),
                       "cold_kernel_ms": round(cold.kernel_ms, 4), "handoff": handoff,
                       "note": "ONE frame on its own: HIP events of the library on the launch stream (ms_per_step is the rate of the "
