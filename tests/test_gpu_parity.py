@@ -76,6 +76,12 @@ def check_whitted(dev, sc, cfg, tol=2e-6, counters=COUNTERS, max_stack=False):
         for k in counters:  # what the final frame traced, query by query: redone pixels count once, stale entries visited count
             assert getattr(first[2], k) == getattr(o_st, k), "literal " + k
         assert first[2].max_stack >= o_st.max_stack  # (the deepest stack of anything traced, speculative passes included)
+        # ... and the instantiation without counters - the one bench.py times, and the only one that may repair with feeler
+        # teams (whitted_level.inc) - renders the same bits
+        plain_cfg = p3d.Config.from_buffer_copy(bytes(cfg))
+        plain_cfg.collect_stats = 0
+        plain = dev.render(plain_cfg)
+        assert_bit_identical(plain[:2], (o_rgb, o_hit), "literal hit_stack, kernels without counters")
         cfg = per_pixel(cfg)
         rgb, hit, st = dev.render(cfg)
     else:
