@@ -1065,6 +1065,53 @@ __global__ void __launch_bounds__(kBlock) handoff_check_list_kernel(const Render
   }
 }
 
+// Round 1 of the hand-off as a LIGHT launch.  List B holds the successors of the units whose leftover changed in round 0; nearly
+// all of them only need their first closest hit re-traced on the new leftover to find that nothing changes.  Until round 4 that was
+// done by the work-list instantiation of whitted_kernel (LIT = 2: the whole Whitted chain, 128 VGPRs + scratch), whose few waves had
+// to wait for a double-width slot among the other frames' pass-1 waves; this kernel only checks, and passes the rare entry whose hit
+// does change (or that asks for no check) on to list C, which the persistent workgroup behind it renders again.
+template <bool LDS, bool SPILL, bool STATS = false>
+__global__ void __launch_bounds__(kBlock) handoff_check_entries_kernel(const RenderParams P) {
+  extern __shared__ float4 smem[];
+  const Handoff& H = P.hand;
+  uint32_t n = __hip_atomic_load(H.n_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  n = n > H.list_cap ? H.list_cap : n;
+  if ((size_t)blockIdx.x * H.lanes >= n) return;  // nothing on the list for this workgroup: leave before the scene is staged
+  const uint32_t lane = threadIdx.x;
+  if (H.round_base >= H.max_rounds) {  // work left after the last round allowed: the frame is not the serial one
+    if (lane == 0) atomicOr(P.status, kHoErrNoFixedPoint);
+    return;
+  }
+  if (H.count && blockIdx.x == 0 && lane == 0) atomicOr(&H.counters[kHoRound1], 1u);
+  DevScene sc = P.sc;
+  stage_scene<LDS, false>(sc, P, smem);
+  Stack st;
+  stack_bind(st, smem, P.lds_scene_f4, lane, P.stack_cap, P.spill, P.level_stride, blockIdx.x * kBlock + lane);
+  for (uint32_t chunk = blockIdx.x; (size_t)chunk * H.lanes < n; chunk += gridDim.x) {
+    const uint32_t i = chunk * H.lanes + lane;
+    if (lane >= H.lanes || i >= n) continue;
+    const uint32_t* e = reinterpret_cast<const uint32_t*>(H.list_in + i);
+    const uint32_t unit = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t pred = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t slot_count = __hip_atomic_load(e + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t flags = __hip_atomic_load(e + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const UnitPlace up = place_of_unit(P, unit);
+    if (!up.valid) continue;
+    if (flags & 1u) {
+      Counters<STATS> ct;
+      ct.clear();
+      seed_stack<SPILL>(st, H, pred, slot_count, ct);
+      if (H.count) atomicAdd(&H.counters[kHoChecked], 1u);
+      const float4 now = first_closest_hit<SPILL, !LDS>(P, sc, st, up.x, up.y, P.antialiasing ? H.first_sample[unit] : 0u, ct);
+      if (same_first(now, H.first[unit])) {  // nothing this unit computes can differ
+        replace_ch0_counters<STATS>(H, unit, ct, P.stats);
+        continue;
+      }
+    }
+    handoff_append(H.list_out, H.n_out, H.list_cap, P.status, make_uint4(unit, pred, slot_count, 0u));  // rendered again by the launch behind this one
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Batched queries (unit-level parity of the traversal back ends)
 // ---------------------------------------------------------------------------

@@ -113,6 +113,10 @@ inline uint32_t round1_lanes() {  // list entries per wave of the round-1 launch
   }();
   return v;
 }
+inline bool light_round1_on() {  // P3D_LIGHT_ROUND1=0: round 1 by the work-list instantiation of whitted_kernel, as until round 4 (A/B runs)
+  static const bool v = [] { const char* e = getenv("P3D_LIGHT_ROUND1"); return !e || atoi(e) != 0; }();
+  return v;
+}
 inline bool takeover_rounds() {  // P3D_TAKEOVER=1: no launch of its own for the fixed-point rounds (measured: no gain, r04 experiments)
   static const bool v = [] { const char* e = getenv("P3D_TAKEOVER"); return e && atoi(e) != 0; }();
   return v;
@@ -580,6 +584,11 @@ hipError_t launch_literal_variant(int lit, bool ghosts, bool aa, bool stats, con
       return hipErrorInvalidValue;
     }
   }
+  if (lit == 5) {  // round 1 as a light launch: check the entries of list B, pass the few that change on to list C
+    if (stats) hipLaunchKernelGGL((handoff_check_entries_kernel<LDS, SPILL, true>), dim3(blocks), dim3(kBlock), lds, st, P);
+    else hipLaunchKernelGGL((handoff_check_entries_kernel<LDS, SPILL, false>), dim3(blocks), dim3(kBlock), lds, st, P);
+    return hipGetLastError();
+  }
   if (lit == 3) {
     if constexpr (!LDS) {  // (only scenes traversed from global memory announce: p3d_render_tile_device)
       if (stats) hipLaunchKernelGGL((handoff_check_list_kernel<LDS, SPILL, true>), dim3(blocks), dim3(kBlock), lds, st, P);
@@ -708,7 +717,8 @@ int finish_stats(p3d_scene* s, hipStream_t st, p3d_stats* stats, bool literal) {
   if (literal) {
     uint32_t c[kHoNumCounters];
     P3D_HIP(hipMemcpy(c, s->ho_counters.p, sizeof(c), hipMemcpyDeviceToHost));
-    if (getenv("P3D_PRINT_HANDOFF")) std::fprintf(stderr, "handoff: checked %u redone %u rounds %u pool %u lists A %u B %u C %u D %u check_n %u round0 %u round1 %u\n", c[kHoChecked], c[kHoRedone], c[kHoRounds], c[kHoPoolTop], c[kHoListA], c[kHoListB], c[kHoListC], c[kHoListD], c[kHoCheckN], c[kHoRound0], c[kHoRound1]);
+    static const bool print_handoff = getenv("P3D_PRINT_HANDOFF") != nullptr;  // (profiles/tools/ab/lists_probe.py)
+    if (print_handoff) std::fprintf(stderr, "handoff: checked %u redone %u rounds %u pool %u lists A %u B %u C %u D %u check_n %u round0 %u round1 %u\n", c[kHoChecked], c[kHoRedone], c[kHoRounds], c[kHoPoolTop], c[kHoListA], c[kHoListB], c[kHoListC], c[kHoListD], c[kHoCheckN], c[kHoRound0], c[kHoRound1]);
     stats->handoff_checked = c[kHoChecked]; stats->handoff_redone = c[kHoRedone]; stats->handoff_rounds = c[kHoRounds] + (c[kHoRound0] ? 1 : 0) + (c[kHoRound1] ? 1 : 0);
   }
   return check_status(s);
@@ -1070,10 +1080,12 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
           P.wf_total = level ? wf_hists + (size_t)(level - 1) * kWfHistWords + kWfBins : nullptr;
           const uint32_t g = level == 0 ? blocks : queue_blocks;
           P.level_stride = g * kBlock;
-          if (want_counts && literal) hipLaunchKernelGGL((wf_level_kernel<true, 1>), dim3(g), dim3(kBlock), lds_bytes, st, P);
-          else if (want_counts) hipLaunchKernelGGL((wf_level_kernel<true, 0>), dim3(g), dim3(kBlock), lds_bytes, st, P);
-          else if (literal) hipLaunchKernelGGL((wf_level_kernel<false, 1>), dim3(g), dim3(kBlock), lds_bytes, st, P);
-          else hipLaunchKernelGGL((wf_level_kernel<false, 0>), dim3(g), dim3(kBlock), lds_bytes, st, P);
+          // (wf_level_kernel keeps its shading state in registers: no cold area behind its stack window)
+          const size_t wf_lds = lds_bytes - (cold_lds ? (size_t)kColdDwords * kBlock * sizeof(float) : 0);
+          if (want_counts && literal) hipLaunchKernelGGL((wf_level_kernel<true, 1>), dim3(g), dim3(kBlock), wf_lds, st, P);
+          else if (want_counts) hipLaunchKernelGGL((wf_level_kernel<true, 0>), dim3(g), dim3(kBlock), wf_lds, st, P);
+          else if (literal) hipLaunchKernelGGL((wf_level_kernel<false, 1>), dim3(g), dim3(kBlock), wf_lds, st, P);
+          else hipLaunchKernelGGL((wf_level_kernel<false, 0>), dim3(g), dim3(kBlock), wf_lds, st, P);
           e = hipGetLastError();
           if (e == hipSuccess && level < cfg->max_depth) {  // put the child rays in bin order for the next level
             hipLaunchKernelGGL(wf_scan_kernel, dim3(1), dim3(1024), 0, st, P.wf_hist);
@@ -1131,19 +1143,24 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       H.list_in = ho_list[round]; H.n_in = ho_counters + kHoListA + round;
       H.list_out = ho_list[round + 1]; H.n_out = ho_counters + kHoListA + round + 1;
       H.persistent = round == 2 ? 1u : 0u;
+      const bool light_round1 = !takeover_rounds() && light_round1_on();
       H.takeover = takeover_rounds() && round == 1 ? 1u : 0u;  // (experiment, off: see Handoff::takeover)
       if (takeover_rounds() && round == 2) continue;
-      H.round_base = (uint32_t)round;
+      // round 1 = a light check of list B (handoff_check_entries_kernel) + the persistent workgroup, which then starts with
+      // round 1's own repairs (list C) before it goes on to the rounds that follow
+      H.round_base = (uint32_t)(light_round1 && round == 2 ? 1 : round);
       // round 0 renders unrelated deep pixels again; entries per wave: see P3D_REDO_LANES above
-      H.lanes = round == 0 ? redo_lanes() : round1_lanes();
+      H.lanes = round == 0 ? redo_lanes() : (round == 1 ? round1_lanes() : kBlock);
       // (round >= 1 works through the successors of units whose leftover changed, a few thousand list entries at most: a small
       // grid with a grid-stride loop - 16 384 workgroups that find nothing take 25 us to come and go, a lone frame waits for them)
-      const uint32_t blocks = round == 2 ? 1u : (round == 1 ? std::min(wide, list_blocks()) : wide);
+      // (round 0 over list A - scenes traversed from global memory - rarely has anything on it: 4 096 workgroups and a
+      // grid-stride loop instead of one workgroup per 64 pixels that comes only to find the list empty, 16 us for a 2048x2048 frame)
+      const uint32_t blocks = round == 2 ? 1u : (round == 1 ? std::min(wide, list_blocks()) : std::min<uint32_t>(wide, 4096u));
       P.level_stride = blocks * kBlock;
       P.tile_blocks = blocks;
       const uint32_t real_cap = H.list_cap;
       if (abl_skip() & 8u) H.list_cap = 0;  // (ablation: the launch happens, every workgroup finds an empty list)
-      const hipError_t e = launch_literal(2, ghosts, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
+      const hipError_t e = launch_literal(light_round1 && round == 1 ? 5 : 2, ghosts, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
       H.list_cap = real_cap;
       if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("hand-off kernel launch: ") + hipGetErrorString(e));
     }
