@@ -32,7 +32,7 @@ constexpr uint32_t kHaloChain = 16;       // slots in front of a row that starts
 constexpr uint32_t kMetaTouched = 1u << 17;
 constexpr uint32_t kNoUnit = 0xffffffffu;
 
-enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoPoolTop, kHoListA, kHoListB, kHoListC, kHoListD, kHoCheckN, kHoRound0, kHoRound1, kHoFinished, kHoNumCounters };
+enum HandoffCounter { kHoChecked = 0, kHoRedone, kHoRounds, kHoPoolTop, kHoListA, kHoListB, kHoListC, kHoListD, kHoCheckN, kHoRound0, kHoRound1, kHoNumCounters };
 constexpr uint32_t kHoErrLeftoverCap = 1u;   // a leftover had more entries than a slot holds, or the leftover pool is full
 constexpr uint32_t kHoErrNoFixedPoint = 2u;  // round bound reached
 constexpr uint32_t kHoErrTrips = 4u;         // sample hand-out loop hit its trip bound (SUB = 4 kernels)
@@ -46,10 +46,6 @@ struct Handoff {
   uint32_t rows;        // tile rows
   uint32_t cap;         // entries per leftover slot
   uint32_t persistent;  // list kernel: one workgroup, loop over rounds until the list stays empty
-  uint32_t takeover;    // list kernel, many workgroups: the one that finishes last goes on like a persistent one (counters[kHoFinished]).
-                        // Built and measured in round 4, off by default: every workgroup needs an agent-scope release fence before it
-                        // counts itself out, which on this chip writes the XCD's L2 back - 256 of those per frame cost more than the
-                        // one-workgroup launch they save (profiles/r04/experiments)
   uint32_t list_cap;
   uint32_t max_rounds;  // rounds (work-list launches + trips of the persistent workgroup) after which a non-empty list is an error
   uint32_t round_base;  // rounds that came before this launch

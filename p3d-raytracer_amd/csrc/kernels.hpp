@@ -475,8 +475,7 @@ __global__ void __launch_bounds__(kBlock, LIT >= 2 ? P3D_LIST_WAVES : (AA ? P3D_
   if (LIT == 2) {  // nothing on the list for this workgroup: leave before the scene is staged
     uint32_t n0 = __hip_atomic_load(P.hand.n_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     n0 = n0 > P.hand.list_cap ? P.hand.list_cap : n0;
-    // (takeover launches: a workgroup without a chunk stays, it may be the last one to finish - unless the list is empty)
-    if (n0 == 0 || (!P.hand.takeover && (size_t)blockIdx.x * P.hand.lanes >= n0)) return;
+    if ((size_t)blockIdx.x * P.hand.lanes >= n0) return;
   }
   const uint32_t lane = threadIdx.x;
   const uint32_t tws = SUB == 4 ? 2u : P.tile_w_shift, ths = SUB == 4 ? 2u : P.tile_h_shift;  // tile = (1 << tws) x (1 << ths) pixels
@@ -538,10 +537,7 @@ __global__ void __launch_bounds__(kBlock, LIT >= 2 ? P3D_LIST_WAVES : (AA ? P3D_
   uint4* list_out = H.list_out;
   uint32_t* n_in_p = H.n_in;
   uint32_t* n_out_p = H.n_out;
-  // LIT == 2: this workgroup goes on alone, round after round, until a list stays empty - the one workgroup of a `persistent`
-  // launch, or the workgroup of a `takeover` launch that finishes last (what the others wrote is complete then)
-  bool sole = LIT == 2 && H.persistent != 0;
-  for (uint32_t round = 0;; ++round) {  // LIT == 2, sole workgroup: a trip per round; otherwise one trip
+  for (uint32_t round = 0;; ++round) {  // LIT == 2 in one persistent workgroup: a trip per round; otherwise one trip
     uint32_t n_in = 0;
     if (LIT == 2) {
       n_in = __hip_atomic_load(n_in_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -551,12 +547,12 @@ __global__ void __launch_bounds__(kBlock, LIT >= 2 ? P3D_LIST_WAVES : (AA ? P3D_
         if (lane == 0) atomicOr(P.status, kHoErrNoFixedPoint);
         break;
       }
-      if (H.count && (sole || blockIdx.x == 0) && lane == 0) {  // rounds that found work: round 1 as a flag (the tile launch's own re-checks raise it too)
+      if (H.count && blockIdx.x == 0 && lane == 0) {  // rounds that found work: round 1 as a flag (the tile launch's own re-checks raise it too)
         if (H.round_base + round == 1) atomicOr(&H.counters[kHoRound1], 1u);
         else atomicAdd(&H.counters[kHoRounds], 1u);
       }
     }
-    for (uint32_t chunk = sole ? 0u : blockIdx.x;; chunk += sole ? 1u : gridDim.x) {  // LIT == 2: 64 list entries per trip
+    for (uint32_t chunk = blockIdx.x;; chunk += gridDim.x) {  // LIT == 2: 64 list entries per trip
       bool active;
       UnitPlace up;
       uint32_t unit = 0, pred = 0, pred_slot_count = 0, flags = 0;
@@ -781,19 +777,8 @@ __global__ void __launch_bounds__(kBlock, LIT >= 2 ? P3D_LIST_WAVES : (AA ? P3D_
       }
       if (LIT != 2) break;
     }
-    if (LIT != 2) break;
-    if (!sole) {
-      if (!H.takeover) break;
-      // the last workgroup of this launch to get here carries on alone (no launch of its own for the rounds that follow,
-      // which almost never find anything: one launch less in the dependent chain of a frame)
-      __threadfence();
-      uint32_t k = 0;
-      if (lane == 0) k = atomicAdd(&H.counters[kHoFinished], 1u);
-      k = __shfl(k, 0, 64);
-      if (k != gridDim.x - 1) break;
-      sole = true;
-    }
-    // next round of the sole workgroup: what was written becomes the work list; the one just done is emptied
+    if (LIT != 2 || !H.persistent) break;
+    // next round of the persistent workgroup: what was written becomes the work list; the one just done is emptied
     __threadfence();
     if (lane == 0) __hip_atomic_store(n_in_p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();

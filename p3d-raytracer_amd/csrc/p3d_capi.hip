@@ -113,14 +113,6 @@ inline uint32_t round1_lanes() {  // list entries per wave of the round-1 launch
   }();
   return v;
 }
-inline bool light_round1_on() {  // P3D_LIGHT_ROUND1=0: round 1 by the work-list instantiation of whitted_kernel, as until round 4 (A/B runs)
-  static const bool v = [] { const char* e = getenv("P3D_LIGHT_ROUND1"); return !e || atoi(e) != 0; }();
-  return v;
-}
-inline bool takeover_rounds() {  // P3D_TAKEOVER=1: no launch of its own for the fixed-point rounds (measured: no gain, r04 experiments)
-  static const bool v = [] { const char* e = getenv("P3D_TAKEOVER"); return e && atoi(e) != 0; }();
-  return v;
-}
 inline uint32_t list_blocks() {  // workgroups of the round-1 work-list launch (P3D_LIST_BLOCKS overrides)
   static const uint32_t v = [] {
     const char* e = getenv("P3D_LIST_BLOCKS");
@@ -1119,10 +1111,12 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     if (literal && stats && pass == 0) P3D_HIP(hipEventRecord(s->ev_mid, st));
   }
   if (literal) {
-    // Work-list launches over the whole tile: A (units whose first closest hit changed under the predecessor's pass-1
-    // leftover) is rendered again and writes B (successors of units whose own leftover changed); B is checked, and
-    // rendered again where needed, into C; whatever is left after that — almost never anything — is iterated to the
-    // fixed point by one persistent workgroup (C -> D -> C ...).
+    // The rounds behind pass 1, over the whole tile.  Round 0: the units whose first closest hit changes under the predecessor's
+    // pass-1 leftover are rendered again - over the tiles, by the launch above (LDS-staged scenes: it wrote list B directly), or
+    // from list A, which the check launch fills (scenes traversed from global memory) - and put the successors of the units whose
+    // own leftover changed on list B.  Round 1: a light launch re-traces the first closest hits of list B's units on the new
+    // leftovers and passes the rare one that changes on to list C; one persistent workgroup renders list C again and iterates
+    // whatever is left after that - almost never anything - to the fixed point (C -> D -> C ...).
     P.x0 = tile->x0; P.w = tile->w; P.h = tile->h; P.row0 = 0; P.y0 = tile->y0;
     P.rgb = d_rgb; P.hit_id = d_hit; P.rgb8 = d_rgb8;
     P.sched = nullptr; P.tile_cost = nullptr;
@@ -1130,7 +1124,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     // (one workgroup per 64 pixels at most: with few list entries per wave a list of 1 % of the pixels still gets a wave
     // per chunk; workgroups without a chunk leave at once)
     const uint32_t wide = std::max<uint32_t>(1, std::min<uint32_t>(max_threads / kBlock, std::max<uint32_t>(64, H.n_units / kBlock)));
-    if (H.check_list && !(abl_skip() & 1u)) {  // round 1 of the hand-off over the units pass 1 announced: writes list A
+    if (H.check_list && !(abl_skip() & 1u)) {  // the check of round 0 over the units pass 1 announced: writes list A
       H.list_out = ho_list[0]; H.n_out = ho_counters + kHoListA;
       P.level_stride = wide * kBlock;
       P.tile_blocks = wide;
@@ -1143,12 +1137,8 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       H.list_in = ho_list[round]; H.n_in = ho_counters + kHoListA + round;
       H.list_out = ho_list[round + 1]; H.n_out = ho_counters + kHoListA + round + 1;
       H.persistent = round == 2 ? 1u : 0u;
-      const bool light_round1 = !takeover_rounds() && light_round1_on();
-      H.takeover = takeover_rounds() && round == 1 ? 1u : 0u;  // (experiment, off: see Handoff::takeover)
-      if (takeover_rounds() && round == 2) continue;
-      // round 1 = a light check of list B (handoff_check_entries_kernel) + the persistent workgroup, which then starts with
-      // round 1's own repairs (list C) before it goes on to the rounds that follow
-      H.round_base = (uint32_t)(light_round1 && round == 2 ? 1 : round);
+      // (the persistent workgroup starts with round 1's own repairs, list C, before it goes on to the rounds that follow)
+      H.round_base = (uint32_t)(round == 2 ? 1 : round);
       // round 0 renders unrelated deep pixels again; entries per wave: see P3D_REDO_LANES above
       H.lanes = round == 0 ? redo_lanes() : (round == 1 ? round1_lanes() : kBlock);
       // (round >= 1 works through the successors of units whose leftover changed, a few thousand list entries at most: a small
@@ -1160,7 +1150,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       P.tile_blocks = blocks;
       const uint32_t real_cap = H.list_cap;
       if (abl_skip() & 8u) H.list_cap = 0;  // (ablation: the launch happens, every workgroup finds an empty list)
-      const hipError_t e = launch_literal(light_round1 && round == 1 ? 5 : 2, ghosts, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
+      const hipError_t e = launch_literal(round == 1 ? 5 : 2, ghosts, cfg->antialiasing != 0, lds_scene, want_counts, P, blocks, lds_bytes, st);
       H.list_cap = real_cap;
       if (e != hipSuccess) return fail(P3D_ERR_NO_DEVICE, std::string("hand-off kernel launch: ") + hipGetErrorString(e));
     }
