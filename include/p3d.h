@@ -451,7 +451,8 @@ int p3d_host_scene_desc(p3d_host_scene* hs, int build_bvh, int build_grid,
  * The forwards exist so that code written against the reference's classes compiles and gives the reference's
  * answers; each call is a kernel launch for ONE ray (about 10 us).  Anything that asks more than a handful of
  * questions should ask them in one batch: p3d_trace_closest / p3d_trace_any / p3d_object_intercepts /
- * p3d_object_normal / p3d_skybox_color take n rays per call. */
+ * p3d_object_normal / p3d_skybox_color take n rays per call, and so do the array overloads of BVH::intersect_bvh /
+ * BVH::bool_intersect_bvh on the host class (accel_build.hpp). */
 int p3d_host_scene_bind_device(p3d_host_scene* hs, p3d_scene* scene);
 /* 1 if a cubemap is loaded: the `.p3f` had an `env <dir>` line (scene.cpp:605-610) and the folder was found (relative to
  * the working directory, as in the reference, or next to the scene file), or p3d_host_scene_load_skybox was called. */

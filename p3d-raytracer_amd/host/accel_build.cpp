@@ -46,6 +46,45 @@ bool BVH::bool_intersect_bvh(Ray ray) {
   return p3d_trace_any(dev_, P3D_ACCEL_BVH, 1, o, d, &occ) == P3D_OK && occ != 0;
 }
 
+// ... and as batches: n rays, one launch (p3d_trace_closest / p3d_trace_any take them as they are)
+namespace {
+void pack_rays(const Ray* rays, size_t n, std::vector<float>& o, std::vector<float>& d) {
+  o.resize(3 * n);
+  d.resize(3 * n);
+  for (size_t i = 0; i < n; ++i) {
+    o[3 * i] = rays[i].origin.x; o[3 * i + 1] = rays[i].origin.y; o[3 * i + 2] = rays[i].origin.z;
+    d[3 * i] = rays[i].direction.x; d[3 * i + 1] = rays[i].direction.y; d[3 * i + 2] = rays[i].direction.z;
+  }
+}
+}  // namespace
+bool BVH::intersect_bvh(const Ray* rays, size_t n, bool* hit, Object** hit_obj, Vector* hit_point) {
+  if (!dev_) { fail(P3D_ERR_NO_DEVICE, "BVH::intersect_bvh: no device scene bound (BVH::bindDevice)"); return false; }
+  if (n == 0) return true;
+  if (!rays || !hit || n > 0xffffffffull) { fail(P3D_ERR_INVALID, "BVH::intersect_bvh: bad batch"); return false; }
+  std::vector<float> o, d, hp(3 * n);
+  std::vector<int32_t> id(n, -1);
+  pack_rays(rays, n, o, d);
+  if (p3d_trace_closest(dev_, P3D_ACCEL_BVH, (uint32_t)n, o.data(), d.data(), id.data(), nullptr, hp.data()) != P3D_OK) return false;
+  for (size_t i = 0; i < n; ++i) {
+    hit[i] = id[i] >= 0;
+    if (!hit[i]) continue;
+    if (hit_obj && (size_t)id[i] < scene_order_.size()) hit_obj[i] = scene_order_[id[i]];
+    if (hit_point) hit_point[i] = Vector(hp[3 * i], hp[3 * i + 1], hp[3 * i + 2]);
+  }
+  return true;
+}
+bool BVH::bool_intersect_bvh(const Ray* rays, size_t n, bool* hit) {
+  if (!dev_) { fail(P3D_ERR_NO_DEVICE, "BVH::bool_intersect_bvh: no device scene bound (BVH::bindDevice)"); return false; }
+  if (n == 0) return true;
+  if (!rays || !hit || n > 0xffffffffull) { fail(P3D_ERR_INVALID, "BVH::bool_intersect_bvh: bad batch"); return false; }
+  std::vector<float> o, d;
+  std::vector<uint8_t> occ(n, 0);
+  pack_rays(rays, n, o, d);
+  if (p3d_trace_any(dev_, P3D_ACCEL_BVH, (uint32_t)n, o.data(), d.data(), occ.data()) != P3D_OK) return false;
+  for (size_t i = 0; i < n; ++i) hit[i] = occ[i] != 0;
+  return true;
+}
+
 // grid.cpp:71-151 / 154-208 as single queries on the device scene
 bool Grid::Traverse(Ray& ray, Object** hitobject, Vector& hitpoint) {
   if (!dev_) { fail(P3D_ERR_NO_DEVICE, "Grid::Traverse: no device scene bound (Grid::bindDevice)"); return false; }

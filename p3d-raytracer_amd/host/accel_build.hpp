@@ -25,6 +25,10 @@ class BVH {
   void bindDevice(::p3d_scene* dev) { dev_ = dev; }
   bool intersect_bvh(Ray ray, Object** hit_obj, Vector& hit_point);
   bool bool_intersect_bvh(Ray ray);
+  // The same two queries for n rays in ONE launch (the single-ray forms above cost a launch each, about 10 us): hit[i] = the
+  // return value for rays[i]; hit_obj / hit_point (may be null) are filled where hit[i].  false + p3d_last_error() if the call failed.
+  bool intersect_bvh(const Ray* rays, size_t n, bool* hit, Object** hit_obj, Vector* hit_point);
+  bool bool_intersect_bvh(const Ray* rays, size_t n, bool* hit);
   const std::vector<p3d_bvh_node>& flatNodes() const { return nodes_; }
   const std::vector<uint32_t>& primOrder() const { return order_; }  // permuted objs (bvh.cpp:84)
   uint32_t maxDepth() const { return max_depth_; }

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "accel_build.hpp"
@@ -48,10 +49,12 @@ int main(int argc, char** argv) {
                 a.direction.x, a.direction.y, a.direction.z, b.origin.x, b.origin.y, b.origin.z, b.direction.x, b.direction.y, b.direction.z);
   }
   const int n_obj = hc.scene->getNumObjects();
+  std::vector<Ray> batch;
   for (int k = 0; k < 64; ++k) {
     Ray r = cam->PrimaryRay(Vector(rnd() * cam->GetResX(), rnd() * cam->GetResY(), 0));
     if (k % 3 == 0) r.direction = r.direction * (0.5f + 3 * rnd());  // unnormalised directions (Q8)
     const Ray r0 = r;
+    batch.push_back(r0);
     const int obj = k % n_obj;
     float t = -1.0f;
     const bool hit = hc.scene->getObject(obj)->intercepts(r, t);
@@ -75,6 +78,21 @@ int main(int argc, char** argv) {
     Ray g2 = r0;
     std::printf("GRID %a %a %a %a %a %a %d %a %a %a %d\n", r0.origin.x, r0.origin.y, r0.origin.z, r0.direction.x, r0.direction.y, r0.direction.z,
                 id, hp.x, hp.y, hp.z, (int)hc.grid->Traverse(g2));
+  }
+  {  // the batched forms of the two BVH queries: the same rays in ONE launch each, printed like the single-ray lines
+    const size_t n = batch.size();
+    std::vector<Object*> objs(n, nullptr);
+    std::vector<Vector> hps(n, Vector(0, 0, 0));
+    std::unique_ptr<bool[]> hit(new bool[n]), occ(new bool[n]);
+    if (!hc.bvh->intersect_bvh(batch.data(), n, hit.get(), objs.data(), hps.data())) die("batched intersect_bvh");
+    if (!hc.bvh->bool_intersect_bvh(batch.data(), n, occ.get())) die("batched bool_intersect_bvh");
+    for (size_t k = 0; k < n; ++k) {
+      int id = -1;
+      for (int i = 0; hit[k] && i < n_obj; ++i) if (hc.scene->getObject(i) == objs[k]) id = i;
+      const Ray& r0 = batch[k];
+      std::printf("BVH %a %a %a %a %a %a %d %a %a %a %d\n", r0.origin.x, r0.origin.y, r0.origin.z, r0.direction.x, r0.direction.y, r0.direction.z,
+                  id, hps[k].x, hps[k].y, hps[k].z, (int)occ[k]);
+    }
   }
   if (argc > 2) {
     if (!hc.scene->LoadSkybox(argv[2])) die("LoadSkybox");
