@@ -360,12 +360,20 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
   s->off_normals = (uint32_t)blob.size();
   for (uint32_t i = 0; i < d->n_prims; ++i) blob.push_back(make_float4(d->prims[i].n[0], d->prims[i].n[1], d->prims[i].n[2], 0.f));
   s->off_mats = (uint32_t)blob.size();
+  auto plain = [](float c) { return c >= 0.0f && c <= 1e15f; };
+  bool lights_plain = true;
+  for (uint32_t i = 0; i < d->n_lights; ++i)
+    lights_plain = lights_plain && plain(d->lights[i].color[0]) && plain(d->lights[i].color[1]) && plain(d->lights[i].color[2]);
   for (uint32_t i = 0; i < d->n_materials; ++i) {
     const p3d_material& m = d->materials[i];
     blob.push_back(make_float4(m.diff_color[0], m.diff_color[1], m.diff_color[2], m.diffuse));
     blob.push_back(make_float4(m.spec_color[0], m.spec_color[1], m.spec_color[2], m.specular));
     blob.push_back(make_float4(m.shine, m.transmittance, m.refr_index, m.reflection));
-    blob.push_back(make_float4(m.emission[0], m.emission[1], m.emission[2], 0.f));
+    // .w: the material's specular term is provably multiplied by an exact zero - Ks == 0 - and provably finite and
+    // non-negative whatever the geometry (0 <= shine < inf, specular colour and every light colour in [0, 1e15]): the kernels
+    // then leave the pow(H.N, shine) of main.cpp:224 out for Blinn cosines <= 1 (whitted_level.inc), same bits
+    blob.push_back(make_float4(m.emission[0], m.emission[1], m.emission[2], (lights_plain && m.specular == 0.0f && m.shine >= 0.0f && m.shine < INFINITY &&
+                                                                              plain(m.spec_color[0]) && plain(m.spec_color[1]) && plain(m.spec_color[2])) ? 1.0f : 0.0f));
   }
   s->off_lights = (uint32_t)blob.size();
   for (uint32_t i = 0; i < d->n_lights; ++i) {
