@@ -117,6 +117,29 @@ def workload_setup(name, p3d):
             -512, "cornell.p3f 512x512, path tracer 16 spp, BVH (BASELINE configs[2] scene, reduced spp)")
 
 
+def frame_valu_instructions(summary, literal):
+    """VALU wave-instructions of all launches of ONE frame of the profiled stack mode, from a PMC summary: the kernels that ran at
+    least about once per traced frame (the one-off counting and schedule-building launches of the warm-up did not), without the
+    launches of the OTHER stack mode (a profiled bench run also times its per-pixel / literal counterpart: `whitted_kernel`'s
+    seventh template argument, LIT, is 0 for the per-pixel stack)."""
+    import re
+    dom_calls = summary["dominant"].get("calls", 1)
+    total = 0.0
+    for name, v in summary.get("kernels", {}).items():
+        c = v.get("counters", {}).get("SQ_INSTS_VALU")
+        if not c or v.get("calls", 0) < 0.5 * dom_calls or name.startswith("__amd_rocclr"):
+            continue
+        m = re.match(r"whitted_kernel<(.*)>", name)
+        if m:
+            lit = m.group(1).split(",")[6].strip()
+            if (lit == "0") == bool(literal):
+                continue
+        elif not literal and not name.startswith("pt_kernel"):
+            continue
+        total += c["mean"] * v["calls"] / dom_calls
+    return total
+
+
 def kernel_source_hash():
     """SHA-256 over the device sources: a PMC summary under profiles/ is only quoted for the kernels it was taken from."""
     h = hashlib.sha256()
@@ -449,6 +472,9 @@ def main():
             achieved = insts / (dom_ms * 1e-3) / 1e9  # G wave-instructions / s
             peak = SIMDS * CLOCK_HZ / VALU_CYCLES / 1e9
             traffic = k.get("hbm_bytes")
+            # every launch of a frame (hand-off launches included), not only the dominant one: the kernels of the summary that ran
+            # about once per traced frame (the one-off counting and schedule-building launches of the warm-up do not)
+            frame_insts = frame_valu_instructions(summary, literal) or insts
             roof.update({"bound": "valu_issue", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "Gwave-instr/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "hbm": {"achieved_GBps": round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic else None, "peak_GBps": HBM_PEAK_GBPS,
@@ -457,7 +483,10 @@ def main():
                          "rocprof_avg_ms": k.get("avg_ms"), "source": src,
                          "scope": "the dominant kernel of ONE frame on its own (kernel_ms live from HIP events, rocprof_avg_ms from "
                                   "the committed trace of `bench.py --frames-in-flight 1`)",
-                         "timed_loop_frac_lower_bound": round(insts / (dt / args.steps) / 1e9 / peak, 4) if not dist_on else None})
+                         "timed_loop_frac_lower_bound": round(insts / (dt / args.steps) / 1e9 / peak, 4) if not dist_on else None,
+                         "timed_loop_frac": round(frame_insts / (dt / args.steps) / 1e9 / peak, 4) if not dist_on else None,
+                         "timed_loop_note": "VALU wave-instructions of ALL launches of one frame / ms_per_step / peak: what the chip issues "
+                                            "while `frames_in_flight` frames overlap (the lower bound counts the dominant kernel only)"})
         else:
             roof.update({"bound": "valu_issue", "achieved": None, "peak": round(SIMDS * CLOCK_HZ / VALU_CYCLES / 1e9, 1), "unit": "Gwave-instr/s",
                          "frac": None, "traffic": None, "source": src})
