@@ -454,7 +454,7 @@ __device__ __forceinline__ float4 first_closest_hit(const RenderParams& P, const
 // 1 = pass 1: the pixel starts on an empty stack, the samples of the pixel hand the stack on, and the pixel's leftover,
 // its touched flag and its first closest hit are recorded; 2 = the lanes take units from a work list, seed the stack
 // with the predecessor's leftover, re-trace the first closest hit if the list entry asks for it, and render the unit again
-// if that hit changed; 3 = round 1 of the hand-off over the TILES, check and repair in one launch (LDS-staged scenes): every lane
+// if that hit changed; 3 = round 0 of the hand-off over the TILES, check and repair in one launch (LDS-staged scenes): every lane
 // whose unit starts on a non-empty leftover re-traces its first closest hit on it (what handoff_check_kernel does) and, if that
 // hit changed, renders the unit again in the same wave (what the first work-list launch did with 64 unrelated pixels per
 // wave: the units to repair of one tile are neighbours and walk the scene together - round 3, one box: the list launch
@@ -732,7 +732,7 @@ __global__ void __launch_bounds__(kBlock, LIT >= 2 ? P3D_LIST_WAVES : (AA ? P3D_
             atomicOr(&H.touched[unit >> 5], 1u << (unit & 31u));
           }
           H.meta[unit] = meta;
-          H.meta0[unit] = meta;  // pass 1's record, never changed by a repair (what the tile launch of round 1 reads of its predecessors)
+          H.meta0[unit] = meta;  // pass 1's record, never changed by a repair (what the tile launch of round 0 reads of its predecessors)
         }
 #endif
         if (LIT != 0 && STATS) {
@@ -966,7 +966,7 @@ __global__ void __launch_bounds__(kHaloFindThreads) halo_find_kernel(const Rende
   if (tid < kHaloChain - found) halo_pix[row * kHaloChain + tid] = kNoUnit;
 }
 
-// Round 1 of the hand-off for a whole launch: every unit that touched the stack and whose predecessor left something
+// The check of round 0 of the hand-off for a whole launch: every unit that touched the stack and whose predecessor left something
 // re-traces its first closest hit on that leftover; the units whose hit changed go on the work list of the redo launch.
 template <bool LDS, bool SPILL, bool STATS = false>
 __global__ void __launch_bounds__(kBlock) handoff_check_kernel(const RenderParams P) {

@@ -1015,11 +1015,11 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     if (stats && !literal) P3D_HIP(hipEventRecord(s->ev0, st));
   }
   if (stats && literal) P3D_HIP(hipEventRecord(s->ev_p1, st));  // pass1_ms: the speculative pass on its own
-  // Round 1 of the hand-off over an LDS-staged scene: check AND repair over the tiles in one launch (whitted_kernel LIT = 3)
+  // Round 0 of the hand-off over an LDS-staged scene: check AND repair over the tiles in one launch (whitted_kernel LIT = 3)
   // instead of a check launch that fills a list and a launch that renders the listed units again, 64 unrelated pixels per wave.
   const bool repair_tiles = literal && lds_scene && !per_level;
   const bool ghosts = s->zero_weight_reflections;
-  std::vector<const uint32_t*> band_sched;  // the tile schedule pass 1 used for each band: the tile launch of round 1 takes the same order
+  std::vector<const uint32_t*> band_sched;  // the tile schedule pass 1 used for each band: the tile launch of round 0 takes the same order
   // pass: 0 = the render launches (LITERAL: pass 1, everything on an empty stack); 1 = LITERAL only: the check launches
   for (int pass = 0; pass < (literal ? 2 : 1); ++pass) {
     if (pass == 1 && (abl_skip() & 1u)) break;
