@@ -802,6 +802,34 @@ def test_planes_boxes_and_glass(accel):
         assert st.plane_tests > 0 and (hit == 0).any() and (hit == 1).any()
 
 
+@pytest.mark.parametrize("matte,lights", [
+    ("0.8 0.7 0.2 0.9  0.3 0.6 0.9 0 40", "0.9 0.8 0.7"),      # Ks = 0: the kernels leave the Blinn power out (p3d_capi.hip material flag)
+    ("0.8 0.7 0.2 0.9  0.3 0.6 0.9 0 1e30", "0.9 0.8 0.7"),    # ... also for a shine that drives every power below 1 to zero
+    ("0.8 0.7 0.2 0.9  0.3 0.6 0.9 0 0", "0.9 0.8 0.7"),       # ... and for shine 0 (pow(x, 0) = 1, pow(0, 0) = 1)
+    ("0.8 0.7 0.2 0.9  0.3 0.6 0.9 -0.0 40", "0.9 0.8 0.7"),   # Ks = -0 compares equal to 0: flagged as well, the products' signs must survive
+    ("0.8 0.7 0.2 0.9  0.3 0.6 0.9 0 40", "0.9 -0.8 0.7"),     # a negative light colour: NOT flagged, the power is computed
+    ("0.8 0.7 0.2 0.9  0.3 -0.6 0.9 0 40", "0.9 0.8 0.7"),     # a negative specular colour: not flagged
+    ("0.8 0.7 0.2 0.9  0.3 0.6 0.9 0 -3", "0.9 0.8 0.7"),      # a negative shine (pow(0, -3) = inf, times Ks = 0 is a NaN): not flagged
+])
+def test_materials_whose_specular_term_is_multiplied_away(matte, lights, tmp_path):
+    """main.cpp:224 computes pow(H.N, shine) for every unshadowed light and main.cpp:232 multiplies the specular sum by Ks.
+    For Ks == 0 with well-behaved colours and shine the kernels skip the power (same bits by construction: DESIGN.md section 4,
+    experiments r04 section 13); every variant - flagged or not - must still be the oracle's frame bit for bit."""
+    path = str(tmp_path / "matte.p3f")
+    with open(path, "w") as f:
+        f.write("\n".join([
+            "bclr 0.1 0.2 0.3", "v", "from 3.2 2.1 1.9", "at 0 0 0.2", "up 0 0 1", "angle 45", "hither 0.01", "resolution 160 128", "aperture 0", "focal 1",
+            "l 4 3 5 %s" % lights, "l -3 2 4 0.5 0.6 0.7",
+            "f %s 0 1 0 0 0" % matte,
+            "p 3", "-3 -3 0", "3 -3 0", "3 3 0", "p 3", "-3 -3 0", "3 3 0", "-3 3 0",
+            "s 0.9 -0.4 0.45 0.45",
+            "f 0.9 0.9 0.9 0.4  1 1 1 0.6 60 0 1 0 0 0",
+            "s 0 0.3 0.5 0.5", "s -0.9 -0.6 0.3 0.3"]) + "\n")
+    dev, sc = _pair(path)
+    for accel in (p3d.ACCEL_NONE, p3d.ACCEL_BVH):
+        check_whitted(dev, sc, p3d.whitted_config(accel=accel, max_depth=3))
+
+
 @pytest.mark.parametrize("name,spp_sqrt,lens,crop", [("cfg3", 16, None, (448, 440, 96, 96)),
                                                      ("cfg5", 64, (10.0, 1.0), (500, 300, 24, 24))])
 def test_baseline_path_tracer_configs_at_full_sampling(name, spp_sqrt, lens, crop):

@@ -274,3 +274,26 @@ def test_jpeg_decoder_matches_pil_on_other_baseline_files_and_refuses_the_rest(t
     assert "progressive" in str(e.value)
     with pytest.raises(p3d.P3DError):
         through_library(lambda p: open(p, "wb").write(b"\xff\xd8\xff\xe0 not a jpeg at all"))
+
+
+def test_bench_counts_the_instructions_of_a_frame_of_the_profiled_stack_mode_only():
+    """bench.py `roofline.timed_loop_frac` sums the VALU wave-instructions of every launch of ONE frame from the committed PMC
+    summary.  A profiled literal run also times its per-pixel counterpart (and once each the counting instantiations): those
+    must not be counted.  Checked on a synthetic summary with the kernel names rocprofv3 reports."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def k(calls, valu):
+        return {"calls": calls, "counters": {"SQ_INSTS_VALU": {"mean": valu}}}
+    summary = {"dominant": {"calls": 100, "SQ_INSTS_VALU": 60.0},
+               "kernels": {"whitted_kernel<2, true, false, false, false, 1, 1, false>": k(100, 60.0),   # pass 1
+                           "whitted_kernel<2, true, false, false, false, 1, 3, false>": k(100, 7.0),    # round 0 over the tiles
+                           "whitted_kernel<2, true, false, false, false, 1, 2, false>": k(200, 0.5),    # two work-list launches per frame
+                           "handoff_check_entries_kernel<true, false, false>": k(100, 0.25),
+                           "clear_kernel": k(110, 0.01),
+                           "whitted_kernel<2, true, false, false, false, 1, 0, true>": k(101, 58.0),    # the per-pixel frames of the same run
+                           "whitted_kernel<2, true, true, false, false, 1, 1, false>": k(1, 70.0),      # counting instantiation, once
+                           "sched_build_kernel": k(2, 0.02), "__amd_rocclr_copyBuffer": k(100, 0.001)}}
+    assert abs(bench.frame_valu_instructions(summary, True) - (60.0 + 7.0 + 2 * 0.5 + 0.25 + 0.011)) < 1e-9
+    assert abs(bench.frame_valu_instructions(summary, False) - 58.0 * 1.01) < 1e-9
