@@ -19,10 +19,13 @@ the reference's serial pixel order (tests/test_gpu_parity.py); `per_pixel_stack`
 emptied at every primary sample (one launch, <= 1e-4 from the reference on sphere scenes, identical on the
 100k-triangle scene).  Rays are counted as the reference's frame has them (one traversal query each).
 
-On one GPU the timed loop keeps four frames in flight (--frames-in-flight 4): frame i is rendered by device scene i % 4 on
-stream i % 4 into buffers of its own — the caller-side way to overlap the latency-bound parts of a frame (its slowest
-tiles; the check, redo and fixed-point launches of the hit_stack hand-off, which are short dependent launches) with the
-bulk of the others; every frame is rendered completely, all are finished when the timed region ends.  `frame.kernel_ms` is ONE frame on its own (HIP events inside the library).
+On one GPU the timed loop keeps several frames in flight: frame i is rendered by device scene i % n into buffers of its own
+— the caller-side way to overlap the latency-bound parts of a frame (its slowest tiles; the launches of the hit_stack
+hand-off, which are short dependent launches) with the bulk of the others; every frame is rendered completely, all are
+finished when the timed region ends.  Literal frames (the default): six scenes, pass 1 of frame i on one of two "bulk"
+streams (i % 2) and everything behind it on one of two "tail" streams (p3d_scene_set_tail_stream), four HIP streams = the four
+hardware queues; per-pixel frames (and `--tail-streams 0`): four scenes, whole frames on four streams.
+`frame.kernel_ms` is ONE frame on its own (HIP events inside the library).
 
 Prints ONE JSON line on rank 0.  `roofline` and `cpu_baseline` follow DESIGN.md "Measurement".
 """
@@ -61,7 +64,12 @@ def parse():
                     help="N = 1: consecutive frames go round-robin to this many device scenes (each with its own scratch and "
                          "hand-off records, p3d.h: different scenes are independent) on as many HIP streams, so that the "
                          "latency-bound tail of frame k (its slowest tiles, the redo launch of the literal hand-off) overlaps "
-                         "the bulk of the following frames.  Default 4 on one GPU (1 = every frame waits for the one before), 1 on several.")
+                         "the bulk of the following frames.  Default on one GPU: 6 with tail streams (literal frames), 4 without (1 = every frame waits for the one before); 2 per rank on several.")
+    ap.add_argument("--tail-streams", type=int, default=2,
+                    help="N = 1, literal stack mode: the hit_stack hand-off launches of every frame (everything behind pass 1) go to "
+                         "this many streams of their own (p3d_scene_set_tail_stream) and pass 1 of all frames to --bulk-streams "
+                         "streams, instead of whole frames on --frames-in-flight streams (then 6 frames in flight by default); 0 = off")
+    ap.add_argument("--bulk-streams", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-order", default="cost", choices=["cost", "frame"],
                     help="p3d_config.tile_order: cost = tiles most-expensive-class first (schedule recorded by the first "
@@ -217,12 +225,25 @@ def main():
     # slowest tiles finish and its gather runs.  A rank's stripes are a short launch, as long as its slowest waves whatever the
     # work in it: rank 0 of 8 of the configs[3] frame takes 3.45 ms alone and 2.09 ms per frame with two in flight
     # (an even share of the frame: 1.94 ms) - profiles/r04/experiments/README.md section 8.
-    nfl = max(1, args.frames_in_flight if args.frames_in_flight is not None else (4 if not dist_on else 2))
+    split_ok = not dist_on and args.stack_mode == "literal" and args.tail_streams > 0
+    nfl = max(1, args.frames_in_flight if args.frames_in_flight is not None else ((6 if split_ok else 4) if not dist_on else 2))
     if dist_on:
         nfl = min(nfl, 2)  # (the gather is double-buffered: one scene and stream per slot)
     # (slot 0 stays on the default stream: HIP spreads streams over 4 hardware queues, the default stream has one to
     # itself and the pool streams share the other three — a fourth pool stream would queue behind the first one's launches)
-    flight = [(dev, stream)] + [(p3d.DeviceScene(hs, bvh=True, device=dev_index), torch.cuda.Stream()) for _ in range(nfl - 1)]
+    tail_streams = args.tail_streams if (split_ok and nfl > 1) else 0
+    if tail_streams:
+        # pass 1 of every frame on a few "bulk" streams (two such kernels fill the chip), the dependent hand-off launches behind
+        # it on "tail" streams (p3d_scene_set_tail_stream): a frame's chain of short launches no longer holds up the next
+        # frame's pass 1 on its stream.  Streams are created bulk first: HIP deals them to its hardware queues in that order.
+        bulk = [stream] + [torch.cuda.Stream() for _ in range(max(1, args.bulk_streams) - 1)]
+        tails = [torch.cuda.Stream() for _ in range(tail_streams)]
+        scenes = [dev] + [p3d.DeviceScene(hs, bvh=True, device=dev_index) for _ in range(nfl - 1)]
+        flight = [(scenes[k], bulk[k % len(bulk)]) for k in range(nfl)]
+        for k, sc_ in enumerate(scenes):
+            sc_.set_tail_stream(tails[k % len(tails)])
+    else:
+        flight = [(dev, stream)] + [(p3d.DeviceScene(hs, bvh=True, device=dev_index), torch.cuda.Stream()) for _ in range(nfl - 1)]
 
     # Every rank renders ALL outputs of its stripes into HBM: float RGB + hit IDs (one packed
     # allocation, 16 B/px) and the gamma-corrected u8 image (img_Data, 3 B/px).  Rank 0 collects one
@@ -505,6 +526,7 @@ def main():
                        "outputs_per_rank": "float RGB + hit ID (16 B/px) + u8 image (3 B/px), all written to HBM",
                        "tile_order": args.tile_order,
                        "frames_in_flight": nfl,
+                       "streams": ("%d bulk (pass 1) + %d tail (hand-off launches)" % (len(bulk), len(tails))) if tail_streams else ("%d, whole frames" % nfl),
                        "frames_in_flight_check": ("each slot's last timed frame vs the frame one scene renders alone, all outputs: %s" % flight_check) if flight_check else None,
                        "parallelism": "image rows in %d-row stripes, round-robin over %d GPU(s)%s"
                                       % (stripe_h, world,
@@ -514,7 +536,7 @@ def main():
                                          % ("u8 image" if gather == "u8" else "float RGB + hit IDs", "RCCL" if args.backend == "nccl" else "gloo (host-staged)", B, nfl, gather_check)
                                          if dist_on else "")},
             "value_note": "value = throughput of the timed loop (median of %d repeats of exactly --steps steps) with `frames_in_flight` frames "
-                          "overlapping on as many device scenes and streams; value_single_frame / latency_ms_single_frame = ONE frame rendered "
+                          "overlapping on as many device scenes (streams: config.streams); value_single_frame / latency_ms_single_frame = ONE frame rendered "
                           "alone (HIP events inside the library, mean of %d frames)" % (len(dts), n_probes),
             "frame": {"kernel_ms": round(kernel_ms, 4), "pass1_ms": round(pass1_ms, 4), "handoff_ms": round(handoff_ms, 4),
                       "cold_kernel_ms": round(cold.kernel_ms, 4), "handoff": handoff,

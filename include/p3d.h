@@ -381,6 +381,19 @@ int p3d_render_tile_device(p3d_scene* scene, const p3d_config* cfg, const p3d_ti
                            void* hip_stream, p3d_stats* stats);
 
 /*
+ * The launches behind pass 1 of a P3D_STACK_LITERAL frame - the hit_stack hand-off rounds: a chain of short launches that
+ * depend on each other and carry a few per cent of the frame's work - can be given a stream of their own, so that what the
+ * caller enqueues behind the frame on `hip_stream` (other scenes' frames) is not held up by them: with a tail stream set,
+ * p3d_render_tile_device without `stats` enqueues clear + pass 1 on `hip_stream` and everything behind them on the tail stream
+ * (ordered by an event).  The frame's outputs are complete when the TAIL stream has passed the call: p3d_scene_join makes
+ * `hip_stream` wait for that (host_wait = 0) or the calling thread (host_wait != 0); the next call on the same scene waits by
+ * itself.  NULL switches it off.  No counterpart in the reference (one frame at a time on one core); what `bench.py` uses to
+ * keep the chip busy with several frames in flight.
+ */
+int p3d_scene_set_tail_stream(p3d_scene* scene, void* tail_hip_stream);
+int p3d_scene_join(p3d_scene* scene, void* hip_stream, int host_wait);
+
+/*
  * Errors a kernel detects while it runs (a hit_stack leftover that outgrew its record, a work list of the hit_stack
  * hand-off that overflowed or did not run empty within its round bound, a row of a stripe or sub-rectangle whose
  * incoming hit_stack could not be established, a sample hand-out loop that reached its trip bound and would write pixels

@@ -33,7 +33,7 @@ HANDOFF_COMPACT, HANDOFF_DENSE = 0, 1
 EXPORTS = [
     "p3d_abi_version", "p3d_last_error", "p3d_device_count", "p3d_config_default",
     "p3d_scene_create", "p3d_scene_create_device_bvh", "p3d_scene_destroy", "p3d_scene_set_skybox", "p3d_render_tile", "p3d_render_tile_device",
-    "p3d_scene_status", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
+    "p3d_scene_status", "p3d_scene_set_tail_stream", "p3d_scene_join", "p3d_object_intercepts", "p3d_object_normal", "p3d_skybox_color",
     "p3d_trace_closest", "p3d_trace_any", "p3d_host_scene_load", "p3d_host_scene_destroy",
     "p3d_host_scene_set_resolution", "p3d_host_scene_set_lens", "p3d_host_scene_replicate_lights",
     "p3d_host_scene_desc", "p3d_host_scene_bind_device", "p3d_host_scene_has_skybox", "p3d_host_scene_load_skybox", "p3d_host_scene_skybox_face",
@@ -185,6 +185,8 @@ def lib():
         L.p3d_object_normal.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.p3d_skybox_color.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.p3d_scene_status.argtypes = [C.c_void_p]
+        L.p3d_scene_set_tail_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.p3d_scene_join.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.p3d_debug_scene_limits.argtypes = [C.c_void_p, C.c_void_p]  # csrc/p3d_debug.h: not part of include/p3d.h
         _lib = L
     return _lib
@@ -386,6 +388,18 @@ class DeviceScene:
         """p3d_scene_status: waits for the device, returns P3D_OK (0) or the code of a device-detected error of the
         asynchronous render_device calls since the last check (message: last_error())."""
         return int(self._L.p3d_scene_status(self._h))
+
+    def set_tail_stream(self, stream=None):
+        """p3d_scene_set_tail_stream: the launches behind pass 1 of a literal frame (the hit_stack hand-off) go to `stream` (a
+        torch.cuda.Stream, a raw hipStream_t or None = off); render_device calls without stats then return their outputs when
+        that stream has passed them - see join()."""
+        raw = getattr(stream, "cuda_stream", stream)
+        _check(self._L.p3d_scene_set_tail_stream(self._h, C.c_void_p(raw) if raw else None))
+
+    def join(self, stream=None, host_wait=False):
+        """p3d_scene_join: make `stream` (or, with host_wait, the calling thread) wait for the scene's last frame, tail included."""
+        raw = getattr(stream, "cuda_stream", stream)
+        _check(self._L.p3d_scene_join(self._h, C.c_void_p(raw) if raw else None, 1 if host_wait else 0))
 
     def debug_limits(self, trip_bound=0, max_rounds=0, halo_chain=0, leftover_pool=0):
         """Tests only (csrc/p3d_debug.h, not part of include/p3d.h): shrink limits of THIS scene so that the device-side

@@ -176,6 +176,10 @@ struct p3d_scene {
   uint32_t last_status = 0;              // the bits check_status() found last (what the host-buffer call decides its DENSE retry on)
   p3d_debug_limits dbg{0, 0, 0, 0};      // tests only (csrc/p3d_debug.h): shrunken limits of THIS scene, all 0 = the real ones
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr, ev_p1 = nullptr;
+  // p3d_scene_set_tail_stream: the dependent launches of a LITERAL frame go to a stream of their own
+  hipStream_t tail_stream = nullptr;
+  hipEvent_t ev_tail_go = nullptr, ev_tail_done = nullptr;
+  bool tail_pending = false;  // ev_tail_done was recorded by the last frame: the next launch on this scene waits for it
 };
 
 extern "C" {
@@ -211,6 +215,8 @@ void p3d_scene_destroy(p3d_scene* s) {
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->ev_mid) (void)hipEventDestroy(s->ev_mid);
   if (s->ev_p1) (void)hipEventDestroy(s->ev_p1);
+  if (s->ev_tail_go) (void)hipEventDestroy(s->ev_tail_go);
+  if (s->ev_tail_done) (void)hipEventDestroy(s->ev_tail_done);
   delete s;
 }
 
@@ -494,6 +500,8 @@ static int create_impl(const p3d_scene_desc* d_in, int device, bool device_bvh, 
   P3D_HIP(hipEventCreate(&s->ev1));
   P3D_HIP(hipEventCreate(&s->ev_mid));
   P3D_HIP(hipEventCreate(&s->ev_p1));
+  P3D_HIP(hipEventCreateWithFlags(&s->ev_tail_go, hipEventDisableTiming));
+  P3D_HIP(hipEventCreateWithFlags(&s->ev_tail_done, hipEventDisableTiming));
   *out = s.release();
   return P3D_OK;
 }
@@ -757,6 +765,10 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   P3D_HIP(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)hip_stream;
   s->last_status = 0;
+  if (s->tail_pending) {  // the scene's scratch is in use until the previous frame's tail has run (p3d_scene_set_tail_stream)
+    P3D_HIP(hipStreamWaitEvent(st, s->ev_tail_done, 0));
+    s->tail_pending = false;
+  }
 
   // main.cpp:804-812: without ANTIALIASING the frame loop always calls rayTracing
   const bool pt = cfg->integrator == P3D_PATHTRACE && cfg->antialiasing;
@@ -1020,8 +1032,22 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
   const bool repair_tiles = literal && lds_scene && !per_level;
   const bool ghosts = s->zero_weight_reflections;
   std::vector<const uint32_t*> band_sched;  // the tile schedule pass 1 used for each band: the tile launch of round 0 takes the same order
+  // Everything behind pass 1 is a chain of short dependent launches (p3d_scene_set_tail_stream): on a stream of its own it
+  // does not hold up the launches the caller enqueues behind this frame on `st` - other scenes' pass 1.  Not with `stats`
+  // (the frame is timed as a whole on one stream).
+  bool on_tail = false;
+  auto to_tail = [&]() -> int {
+    if (on_tail || !literal || !s->tail_stream || stats || s->tail_stream == st) return P3D_OK;
+    P3D_HIP(hipEventRecord(s->ev_tail_go, st));
+    P3D_HIP(hipStreamWaitEvent(s->tail_stream, s->ev_tail_go, 0));
+    st = s->tail_stream;
+    on_tail = true;
+    return P3D_OK;
+  };
   // pass: 0 = the render launches (LITERAL: pass 1, everything on an empty stack); 1 = LITERAL only: the check launches
   for (int pass = 0; pass < (literal ? 2 : 1); ++pass) {
+    if (pass == 1)
+      if (int rc = to_tail()) return rc;
     if (pass == 1 && (abl_skip() & 1u)) break;
     if (pass == 1 && H.check_list) break;  // the check runs over pass 1's list, once for the whole tile (below)
     for (uint32_t band0 = 0; band0 < total_bands; band0 += bands_per_launch) {
@@ -1118,6 +1144,7 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
     }
     if (literal && stats && pass == 0) P3D_HIP(hipEventRecord(s->ev_mid, st));
   }
+  if (int rc = to_tail()) return rc;
   if (literal) {
     // The rounds behind pass 1, over the whole tile.  Round 0: the units whose first closest hit changes under the predecessor's
     // pass-1 leftover are rendered again - over the tiles, by the launch above (LDS-staged scenes: it wrote list B directly), or
@@ -1167,7 +1194,31 @@ int p3d_render_tile_device(p3d_scene* s, const p3d_config* cfg, const p3d_tile* 
       P3D_HIP(hipGetLastError());
     }
   }
+  if (on_tail) {
+    P3D_HIP(hipEventRecord(s->ev_tail_done, st));
+    s->tail_pending = true;
+  }
   if (stats) return finish_stats(s, st, stats, literal);
+  return P3D_OK;
+}
+
+int p3d_scene_set_tail_stream(p3d_scene* s, void* hip_stream) {
+  if (!s) return fail(P3D_ERR_INVALID, "p3d_scene_set_tail_stream: null scene");
+  P3D_HIP(hipSetDevice(s->device));
+  if (s->tail_pending) {  // (a frame may still be running on the old tail stream)
+    P3D_HIP(hipEventSynchronize(s->ev_tail_done));
+    s->tail_pending = false;
+  }
+  s->tail_stream = (hipStream_t)hip_stream;
+  return P3D_OK;
+}
+
+int p3d_scene_join(p3d_scene* s, void* hip_stream, int host_wait) {
+  if (!s) return fail(P3D_ERR_INVALID, "p3d_scene_join: null scene");
+  if (!s->tail_pending) return P3D_OK;  // nothing of this scene runs anywhere but on the streams the caller gave it
+  P3D_HIP(hipSetDevice(s->device));
+  if (host_wait) P3D_HIP(hipEventSynchronize(s->ev_tail_done));
+  else P3D_HIP(hipStreamWaitEvent((hipStream_t)hip_stream, s->ev_tail_done, 0));
   return P3D_OK;
 }
 
@@ -1222,6 +1273,7 @@ static int trace_common(p3d_scene* s, uint32_t accel, uint32_t n, const float* o
   if (accel == P3D_ACCEL_GRID && s->dev.n_objs == 0) return fail(P3D_ERR_UNSUPPORTED, "grid over an empty scene");
   if (n == 0) return P3D_OK;
   P3D_HIP(hipSetDevice(s->device));
+  if (int rc = p3d_scene_join(s, nullptr, 1)) return rc;  // (the queries use the scene's scratch on the null stream)
   const size_t in_bytes = (size_t)n * 6 * sizeof(float);
   const size_t out_bytes = (size_t)n * (sizeof(int32_t) + 4 * sizeof(float) + 1) + 256;
   if (int rc = s->q_in.ensure(in_bytes)) return rc;

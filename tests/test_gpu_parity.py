@@ -1186,6 +1186,69 @@ def test_frames_in_flight_on_several_scenes_render_the_same_bits():
             assert (rgb.view(np.uint32) == np.ascontiguousarray(rgb0).view(np.uint32)).all(), (mode, k)
 
 
+def test_hand_off_launches_on_a_tail_stream_render_the_same_bits(tri5k_path):
+    """p3d_scene_set_tail_stream (include/p3d.h), bench.py's default for literal frames: six device scenes, pass 1 of frame i
+    on one of two bulk streams, everything behind it on one of two tail streams, nothing waits until the end.  Every frame must
+    be the frame one scene renders alone, bit for bit - over an LDS-staged scene (round 0 over the tiles) and over one
+    traversed from global memory (check over pass 1's list); p3d_scene_join makes a third stream wait for a frame; a query on
+    the scene (null stream) waits by itself; frames with `stats` do not split and still come out the same."""
+    import torch
+    for path, res, depth in ((scene_path("balls_low.p3f"), 256, 4), (tri5k_path, 128, 3)):
+        hs = p3d.HostScene(path)
+        hs.set_resolution(res, res)
+        n = res * res
+        cfg = p3d.whitted_config(accel=p3d.ACCEL_BVH, max_depth=depth)
+        alone = p3d.DeviceScene(hs, bvh=True)
+        rgb0, hit0, _ = alone.render(cfg)
+        nfl = 6
+        scenes = [p3d.DeviceScene(hs, bvh=True) for _ in range(nfl)]
+        bulk = [torch.cuda.current_stream(), torch.cuda.Stream()]
+        tails = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for k, sc in enumerate(scenes):
+            sc.set_tail_stream(tails[k % 2])
+        bufs = [torch.zeros(n * 16, dtype=torch.uint8, device="cuda") for _ in range(nfl)]
+        tile = scenes[0].full_tile()
+
+        def frame_of(buf):
+            host = buf.cpu().numpy()
+            return host[: n * 12].view(np.float32).reshape(res, res, 3), host[n * 12:].view(np.int32).reshape(res, res)
+
+        def same(buf, what):
+            rgb, hit = frame_of(buf)
+            assert (hit == hit0).all(), what
+            assert (rgb.view(np.uint32) == np.ascontiguousarray(rgb0).view(np.uint32)).all(), what
+        for i in range(5 * nfl):
+            k = i % nfl
+            scenes[k].render_device(cfg, tile, d_rgb=bufs[k].data_ptr(), d_hit=bufs[k].data_ptr() + n * 12, stream=bulk[k % 2].cuda_stream)
+        # a third stream copies scene 0's frame as soon as that frame - tail included - is done
+        side = torch.cuda.Stream()
+        scenes[0].join(side)
+        with torch.cuda.stream(side):
+            copy0 = bufs[0].clone()
+        side.synchronize()
+        same(copy0, "joined copy")
+        torch.cuda.synchronize()
+        for k in range(nfl):
+            assert scenes[k].status() == 0
+            same(bufs[k], k)
+        # a split frame, then at once a query on the same scene (null stream): the query waits for the tail by itself
+        scenes[1].render_device(cfg, tile, d_rgb=bufs[1].data_ptr(), d_hit=bufs[1].data_ptr() + n * 12, stream=bulk[1].cuda_stream)
+        o = np.array([[0.0, 0.0, 5.0]], np.float32)
+        d = np.array([[0.0, 0.0, -1.0]], np.float32)
+        hit_a, _ = scenes[1].trace_closest(p3d.ACCEL_BVH, o, d)
+        hit_b, _ = alone.trace_closest(p3d.ACCEL_BVH, o, d)
+        assert (hit_a == hit_b).all()
+        scenes[1].join(host_wait=True)
+        same(bufs[1], "after the query")
+        # with stats the frame stays on the caller's stream (timed as a whole) and is the same frame
+        rgb, hit, st = scenes[2].render(cfg)
+        assert (hit == hit0).all() and (rgb.view(np.uint32) == np.ascontiguousarray(rgb0).view(np.uint32)).all()
+        scenes[3].set_tail_stream(None)
+        scenes[3].render_device(cfg, tile, d_rgb=bufs[3].data_ptr(), d_hit=bufs[3].data_ptr() + n * 12, stream=bulk[1].cuda_stream)
+        bulk[1].synchronize()
+        same(bufs[3], "tail stream switched off")
+
+
 def test_bench_contract_json_line():
     """bench.py prints ONE JSON line with the driver's keys plus `roofline` and `cpu_baseline`.  The headline value is
     the LITERAL frame (bit-identical to the reference's order); the roofline is a bound (frac <= 1 whenever the PMC
@@ -1205,7 +1268,8 @@ def test_bench_contract_json_line():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["vs_baseline"] is None
     assert d["config"]["rays_per_frame"] == 4944908 and "workload" in d["config"] and "model" not in d["config"]
-    assert d["config"]["stack_mode"] == "literal" and d["frame"]["handoff"]["redone"] == 9995 and d["config"]["frames_in_flight"] == 4 and d["config"]["frames_in_flight_check"].endswith(": ok")
+    assert d["config"]["stack_mode"] == "literal" and d["frame"]["handoff"]["redone"] == 9995 and d["config"]["frames_in_flight"] == 6 and d["config"]["frames_in_flight_check"].endswith(": ok")
+    assert d["config"]["streams"].startswith("2 bulk (pass 1) + 2 tail")  # p3d_scene_set_tail_stream: the default for literal frames
     assert d["frame"]["cold_kernel_ms"] >= d["frame"]["kernel_ms"] * 0.9
     rf = d["roofline"]
     assert rf["bound"] == "valu_issue" and rf["unit"] == "Gwave-instr/s" and abs(rf["peak"] - 1228.8) < 1e-6
