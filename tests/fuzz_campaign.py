@@ -13,7 +13,10 @@ import sys
 import tempfile
 
 import numpy as np
+import torch
 
+if torch.cuda.is_available():  # (torch's HIP runtime first, as tests/conftest.py does: check_whitted renders on torch streams too)
+    torch.cuda.init()
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import p3d_amd as p3d  # noqa: E402

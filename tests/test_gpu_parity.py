@@ -64,6 +64,28 @@ COUNTERS = ("rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "node
             "box_tests", "plane_tests", "shaded_hits", "pixels")
 
 
+_TAIL = []
+
+
+def _render_with_tail_stream(dev, cfg):
+    """The device-buffer call without stats, the launches behind pass 1 on a second stream; -> (rgb, hit) on the host."""
+    import torch
+    if not _TAIL:
+        _TAIL.append(torch.cuda.Stream())
+    tile = dev.full_tile()
+    n = tile.w * tile.h
+    buf = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+    dev.set_tail_stream(_TAIL[0])
+    try:
+        dev.render_device(cfg, tile, d_rgb=buf.data_ptr(), d_hit=buf.data_ptr() + n * 12, stream=torch.cuda.current_stream().cuda_stream)
+        dev.join(host_wait=True)
+        assert dev.status() == 0, p3d.lib().p3d_last_error().decode()
+    finally:
+        dev.set_tail_stream(None)
+    host = buf.cpu().numpy()
+    return host[: n * 12].view(np.float32).reshape(tile.h, tile.w, 3), host[n * 12:].view(np.int32).reshape(tile.h, tile.w)
+
+
 def check_whitted(dev, sc, cfg, tol=2e-6, counters=COUNTERS, max_stack=False):
     """cfg as given: for the BVH under P3D_STACK_LITERAL the frame must be bit-identical to the oracle's serial
     order and every ray / test counter equal to the oracle's.  Then (BVH) the per-pixel stack, or (other back ends) the one render there is: frame within `tol` of the
@@ -76,12 +98,13 @@ def check_whitted(dev, sc, cfg, tol=2e-6, counters=COUNTERS, max_stack=False):
         for k in counters:  # what the final frame traced, query by query: redone pixels count once, stale entries visited count
             assert getattr(first[2], k) == getattr(o_st, k), "literal " + k
         assert first[2].max_stack >= o_st.max_stack  # (the deepest stack of anything traced, speculative passes included)
-        # ... and the instantiation without counters - the one bench.py times, and the only one that may repair with feeler
-        # teams (whitted_level.inc) - renders the same bits
+        # ... and the instantiation without counters - the one bench.py times - renders the same bits
         plain_cfg = p3d.Config.from_buffer_copy(bytes(cfg))
         plain_cfg.collect_stats = 0
         plain = dev.render(plain_cfg)
         assert_bit_identical(plain[:2], (o_rgb, o_hit), "literal hit_stack, kernels without counters")
+        # ... also with the hand-off launches on a tail stream (p3d_scene_set_tail_stream: how bench.py enqueues literal frames)
+        assert_bit_identical(_render_with_tail_stream(dev, plain_cfg), (o_rgb, o_hit), "literal hit_stack, hand-off on a tail stream")
         cfg = per_pixel(cfg)
         rgb, hit, st = dev.render(cfg)
     else:
