@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Which queues pace bench.py's bulk / tail loop (experiments r04 section 19): the loop with three timing events per frame.
+usage (GPU box, from the repository root): python3 profiles/tools/pace_probe.py [frames in flight, default 6]"""
 import os, sys, time, numpy as np, torch
 torch.cuda.init()
 ROOT = os.getcwd(); sys.path.insert(0, ROOT)
